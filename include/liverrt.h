@@ -1,0 +1,241 @@
+/*
+ * liverrt.h -- C ABI of the MI355X-native `hip_ad_rgb` rendering back-end.
+ *
+ * This is the drop-in boundary for the ONE hot path of mmigas/LiverRenderer
+ * (a Mitsuba 3.8 fork): the forward path / volpath sample loop and its PRB
+ * adjoint. Everything below is plain C: opaque handles, POD structs, caller
+ * owned buffers, no exceptions (errors: status code + lrt_last_error()).
+ *
+ * Reference interfaces each entry point replaces (paths relative to the
+ * reference tree):
+ *
+ *   lrt_scene_load_xml / _xml_string    src/core/parser.cpp (mi.load_file / mi.load_string,
+ *                                        `-Dkey=value` defines: src/mitsuba/mitsuba.cpp:161,240-246)
+ *   lrt_scene_from_desc                  mi.load_dict (src/python/python/util.py) -- "from buffers"
+ *   lrt_render                           Integrator::render(scene, sensor, seed, spp, develop, evaluate)
+ *                                        include/mitsuba/render/integrator.h:74,
+ *                                        src/render/integrator.cpp:151-395 (JIT branch :274-388)
+ *   lrt_render_backward                  Integrator::render_backward include/mitsuba/render/integrator.h:253,
+ *                                        src/python/python/ad/integrators/common.py:625-783
+ *   lrt_trace                            the ray-tracing callback seam of the LLVM variants
+ *                                        src/render/scene_native.inl:135-202 (SoA RayHit layout)
+ *   lrt_param_set / lrt_param_get        mi.traverse(scene)[key] (src/media/homogeneous.cpp:146-151,
+ *                                        src/phase/hg.cpp:60-62)
+ *   lrt_film_develop                     HDRFilm::develop src/films/hdrfilm.cpp:306-410
+ *   lrt_last_error                       Throw(...) -> Python RuntimeError
+ *
+ * Threading: one host thread per lrt_scene; device work runs on a private HIP
+ * stream owned by the scene.  All host pointers are caller-owned unless
+ * returned by a *_load / *_from_desc call.
+ */
+#ifndef LIVERRT_H
+#define LIVERRT_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LRT_API __attribute__((visibility("default")))
+
+typedef enum {
+    LRT_OK = 0,
+    LRT_ERR_INVALID = 1,      /* bad argument / unsupported plugin / parse error */
+    LRT_ERR_IO = 2,           /* file not found / unreadable                      */
+    LRT_ERR_DEVICE = 3,       /* HIP runtime failure, or no GPU present           */
+    LRT_ERR_UNSUPPORTED = 4
+} lrt_status;
+
+/* ---------------------------------------------------------------- enums */
+enum { LRT_INTEGRATOR_PATH = 0, LRT_INTEGRATOR_VOLPATH = 1, LRT_INTEGRATOR_PRBVOLPATH = 2 };
+enum { LRT_BSDF_DIFFUSE = 0, LRT_BSDF_DIELECTRIC = 1, LRT_BSDF_BUMPMAP = 2, LRT_BSDF_NULL = 3 };
+enum { LRT_TEX_RGB = 0, LRT_TEX_CHECKERBOARD = 1, LRT_TEX_BITMAP = 2 };
+enum { LRT_PHASE_ISOTROPIC = 0, LRT_PHASE_HG = 1 };
+enum { LRT_EMITTER_AREA = 0, LRT_EMITTER_ENVMAP = 1, LRT_EMITTER_CONSTANT = 2 };
+enum { LRT_SHAPE_MESH = 0, LRT_SHAPE_RECTANGLE = 1 };
+enum { LRT_RFILTER_BOX = 0, LRT_RFILTER_GAUSSIAN = 1, LRT_RFILTER_TENT = 2 };
+
+/* ------------------------------------------------- scene description (POD)
+ * The flattened, plugin-free form of a loaded scene.  Produced by the XML
+ * loader (lrt_scene_desc_get) and accepted by lrt_scene_from_desc; it is also
+ * the data format the CPU oracle under oracle/ consumes, so that both sides
+ * see byte-identical inputs.  All geometry is in world space.               */
+
+typedef struct {
+    int32_t  kind;            /* LRT_SHAPE_*                                       */
+    uint32_t first_face;      /* range into faces[]                                */
+    uint32_t n_faces;
+    int32_t  bsdf;            /* index into bsdfs[], -1: none                      */
+    int32_t  emitter;         /* index into emitters[] (area light), -1: none      */
+    int32_t  interior_medium; /* index into media[], -1: none                      */
+    int32_t  exterior_medium;
+    int32_t  has_normals;     /* per-vertex shading normals present                */
+    int32_t  has_texcoords;
+    int32_t  flip_normals;
+    float    to_world[16];    /* row-major; used by LRT_SHAPE_RECTANGLE sampling   */
+} lrt_shape_desc;
+
+typedef struct {
+    int32_t type;             /* LRT_TEX_*                                         */
+    float   color0[3];        /* RGB value (LRT_TEX_RGB) / checkerboard color0     */
+    float   color1[3];
+    float   to_uv[9];         /* row-major 3x3 affine uv transform                 */
+    int32_t width, height, channels;   /* bitmap: 1 or 3 channels                  */
+    const float *data;        /* bitmap texels, linear, already rounded to the
+                                 storage precision the reference uses (fp16 for
+                                 8/16-bit inputs: src/textures/bitmap.cpp:268-283) */
+} lrt_texture_desc;
+
+typedef struct {
+    int32_t type;             /* LRT_BSDF_*                                        */
+    int32_t reflectance;      /* texture index (diffuse)                           */
+    float   eta;              /* int_ior / ext_ior (dielectric)                    */
+    int32_t nested;           /* bumpmap: nested bsdf index                        */
+    int32_t texture;          /* bumpmap: height texture index                     */
+    float   scale;            /* bumpmap scale                                     */
+} lrt_bsdf_desc;
+
+typedef struct {
+    float   sigma_t[3];
+    float   albedo[3];
+    float   scale;
+    int32_t has_spectral_extinction;
+    int32_t sample_emitters;
+    int32_t phase;            /* LRT_PHASE_*                                       */
+    float   g;
+    char    id[64];           /* XML id, used to form parameter keys               */
+} lrt_medium_desc;
+
+typedef struct {
+    int32_t type;             /* LRT_EMITTER_*                                     */
+    float   radiance[3];      /* area / constant                                   */
+    int32_t shape;            /* area: owning shape                                */
+    float   scale;            /* envmap                                            */
+    float   to_world[16];     /* envmap, row-major                                 */
+    int32_t width, height;    /* envmap: ORIGINAL bitmap resolution (w, h)         */
+    const float *data;        /* envmap: h * w * 3 linear RGB floats               */
+} lrt_emitter_desc;
+
+typedef struct {
+    float   to_world[16];     /* camera-to-world, row-major                        */
+    float   fov_x;            /* horizontal field of view, degrees                 */
+    float   near_clip, far_clip;
+    int32_t medium;           /* medium the sensor sits in, -1: none               */
+} lrt_sensor_desc;
+
+typedef struct {
+    int32_t width, height;
+    int32_t crop_offset_x, crop_offset_y, crop_width, crop_height;
+    int32_t has_alpha;        /* pixel_format rgba                                 */
+    int32_t rfilter;          /* LRT_RFILTER_*                                     */
+    float   rfilter_param;    /* gaussian: stddev; tent: radius                    */
+} lrt_film_desc;
+
+typedef struct {
+    int32_t type;             /* LRT_INTEGRATOR_*                                  */
+    int32_t max_depth;        /* -1: unbounded                                     */
+    int32_t rr_depth;
+    int32_t hide_emitters;
+} lrt_integrator_desc;
+
+typedef struct {
+    uint32_t n_vertices, n_faces, n_shapes, n_bsdfs, n_textures, n_media, n_emitters;
+    const float    *positions;    /* 3 * n_vertices                                */
+    const float    *normals;      /* 3 * n_vertices (zero where absent)            */
+    const float    *texcoords;    /* 2 * n_vertices (zero where absent)            */
+    const uint32_t *faces;        /* 3 * n_faces, global vertex ids                */
+    const uint32_t *face_shape;   /* n_faces                                       */
+    const lrt_shape_desc   *shapes;
+    const lrt_bsdf_desc    *bsdfs;
+    const lrt_texture_desc *textures;
+    const lrt_medium_desc  *media;
+    const lrt_emitter_desc *emitters;
+    lrt_sensor_desc     sensor;
+    lrt_film_desc       film;
+    lrt_integrator_desc integrator;
+    uint32_t sample_count;        /* sampler sample_count (default spp)            */
+    uint32_t sampler_seed;        /* sampler `seed` property (m_base_seed)         */
+} lrt_scene_desc;
+
+/* ----------------------------------------------------------- render call */
+typedef struct {
+    int32_t  integrator;      /* LRT_INTEGRATOR_*, -1: use the scene's             */
+    int32_t  max_depth;       /* -2: use the scene's                               */
+    int32_t  rr_depth;        /* -1: use the scene's                               */
+    int32_t  hide_emitters;   /* -1: use the scene's                               */
+    uint32_t spp;             /* 0: use the scene's sample_count                   */
+    uint32_t seed;
+    /* image-tile sharding (multi-GPU): this call renders only the 32x32 pixel
+       tiles t with t % tile_count == tile_rank, into a full-size zeroed film. */
+    uint32_t tile_rank, tile_count;
+    int32_t  device;          /* HIP device ordinal                                */
+    int32_t  output_on_device;/* film_raw / image are device pointers              */
+} lrt_render_opts;
+
+typedef struct {
+    uint64_t n_samples;       /* camera samples traced                             */
+    uint64_t n_iter;          /* path-loop iterations executed (all paths)         */
+    uint64_t n_shadow;        /* NEE visibility / march ray queries traced         */
+    uint64_t n_launches;      /* iteration-kernel launches                         */
+    double   kernel_ms;       /* sum of iteration-kernel durations (HIP events)    */
+    double   total_ms;        /* whole lrt_render device time (HIP events)         */
+} lrt_render_stats;
+
+typedef struct {
+    float d_sigma_t[3];
+    float d_albedo[3];
+    float d_g;
+} lrt_param_grads;
+
+typedef struct lrt_scene lrt_scene;
+
+LRT_API const char *lrt_last_error(void);
+LRT_API int         lrt_version(void);
+
+LRT_API lrt_status lrt_scene_load_xml(const char *path, const char *const *defines,
+                                      int n_defines, lrt_scene **out);
+LRT_API lrt_status lrt_scene_load_xml_string(const char *xml, const char *base_dir,
+                                             const char *const *defines, int n_defines,
+                                             lrt_scene **out);
+LRT_API lrt_status lrt_scene_from_desc(const lrt_scene_desc *desc, lrt_scene **out);
+LRT_API const lrt_scene_desc *lrt_scene_desc_get(const lrt_scene *scene);
+LRT_API void       lrt_scene_free(lrt_scene *scene);
+
+/* film_raw: crop_h * crop_w * C floats (C = 5 if has_alpha else 4: R,G,B,[A],W),
+ * image:    crop_h * crop_w * (4 if has_alpha else 3) developed floats.
+ * Either may be NULL.  */
+LRT_API lrt_status lrt_render(lrt_scene *scene, const lrt_render_opts *opts,
+                              float *film_raw, float *image);
+LRT_API lrt_status lrt_render_stats_get(const lrt_scene *scene, lrt_render_stats *out);
+LRT_API lrt_status lrt_film_develop(lrt_scene *scene, const float *film_raw, float *image,
+                                    int on_device);
+
+/* Test hook: per-lane radiance of wavefront lanes [lane_begin, lane_begin+n)
+ * of the render described by opts, without film accumulation.
+ * out: n * 4 floats {R, G, B, valid}.  */
+LRT_API lrt_status lrt_render_samples(lrt_scene *scene, const lrt_render_opts *opts,
+                                      uint64_t lane_begin, uint32_t n, float *out);
+
+/* PRB adjoint: d(sum(image * grad_image)) / d(sigma_t, albedo, g) of medium 0. */
+LRT_API lrt_status lrt_render_backward(lrt_scene *scene, const lrt_render_opts *opts,
+                                       const float *grad_image, lrt_param_grads *out);
+
+/* SoA ray queries (layout mirrors RayHit of src/render/scene_native.inl:135-142).
+ * Miss: t = +inf, prim = 0xffffffff.  any_hit: only t (0 on hit, +inf on miss). */
+typedef struct { const float *ox, *oy, *oz, *dx, *dy, *dz, *tmax; } lrt_rays_soa;
+typedef struct { float *t, *u, *v; uint32_t *prim; } lrt_hits_soa;
+LRT_API lrt_status lrt_trace(lrt_scene *scene, const lrt_rays_soa *rays,
+                             const lrt_hits_soa *hits, uint32_t n, int any_hit);
+
+/* Keys follow mi.traverse(): "<medium id>.sigma_t.value" (3 floats),
+ * "<medium id>.albedo.value" (3), "<medium id>.scale" (1),
+ * "<medium id>.phase_function.g" (1; switches the phase to HG when != 0).   */
+LRT_API lrt_status lrt_param_set(lrt_scene *scene, const char *key, const float *v, int n);
+LRT_API lrt_status lrt_param_get(const lrt_scene *scene, const char *key, float *v, int n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LIVERRT_H */

@@ -1,0 +1,150 @@
+"""ctypes binding of libliverrt.so (the C ABI declared in include/liverrt.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` (``make -C
+liverrenderer_amd/csrc``).  There is no CPU fallback: every render call goes to
+the HIP kernels and raises ``RuntimeError`` when no GPU / no library exists.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libliverrt.so")
+
+OK = 0
+INTEGRATOR = {"path": 0, "volpath": 1, "prbvolpath": 2}
+
+
+class ShapeDesc(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("first_face", C.c_uint32), ("n_faces", C.c_uint32), ("bsdf", C.c_int32),
+                ("emitter", C.c_int32), ("interior_medium", C.c_int32), ("exterior_medium", C.c_int32),
+                ("has_normals", C.c_int32), ("has_texcoords", C.c_int32), ("flip_normals", C.c_int32),
+                ("to_world", C.c_float * 16)]
+
+
+class TextureDesc(C.Structure):
+    _fields_ = [("type", C.c_int32), ("color0", C.c_float * 3), ("color1", C.c_float * 3), ("to_uv", C.c_float * 9),
+                ("width", C.c_int32), ("height", C.c_int32), ("channels", C.c_int32), ("data", C.POINTER(C.c_float))]
+
+
+class BsdfDesc(C.Structure):
+    _fields_ = [("type", C.c_int32), ("reflectance", C.c_int32), ("eta", C.c_float), ("nested", C.c_int32),
+                ("texture", C.c_int32), ("scale", C.c_float)]
+
+
+class MediumDesc(C.Structure):
+    _fields_ = [("sigma_t", C.c_float * 3), ("albedo", C.c_float * 3), ("scale", C.c_float),
+                ("has_spectral_extinction", C.c_int32), ("sample_emitters", C.c_int32), ("phase", C.c_int32),
+                ("g", C.c_float), ("id", C.c_char * 64)]
+
+
+class EmitterDesc(C.Structure):
+    _fields_ = [("type", C.c_int32), ("radiance", C.c_float * 3), ("shape", C.c_int32), ("scale", C.c_float),
+                ("to_world", C.c_float * 16), ("width", C.c_int32), ("height", C.c_int32), ("data", C.POINTER(C.c_float))]
+
+
+class SensorDesc(C.Structure):
+    _fields_ = [("to_world", C.c_float * 16), ("fov_x", C.c_float), ("near_clip", C.c_float), ("far_clip", C.c_float),
+                ("medium", C.c_int32)]
+
+
+class FilmDesc(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("crop_offset_x", C.c_int32), ("crop_offset_y", C.c_int32),
+                ("crop_width", C.c_int32), ("crop_height", C.c_int32), ("has_alpha", C.c_int32), ("rfilter", C.c_int32),
+                ("rfilter_param", C.c_float)]
+
+
+class IntegratorDesc(C.Structure):
+    _fields_ = [("type", C.c_int32), ("max_depth", C.c_int32), ("rr_depth", C.c_int32), ("hide_emitters", C.c_int32)]
+
+
+class SceneDesc(C.Structure):
+    _fields_ = [("n_vertices", C.c_uint32), ("n_faces", C.c_uint32), ("n_shapes", C.c_uint32), ("n_bsdfs", C.c_uint32),
+                ("n_textures", C.c_uint32), ("n_media", C.c_uint32), ("n_emitters", C.c_uint32),
+                ("positions", C.POINTER(C.c_float)), ("normals", C.POINTER(C.c_float)), ("texcoords", C.POINTER(C.c_float)),
+                ("faces", C.POINTER(C.c_uint32)), ("face_shape", C.POINTER(C.c_uint32)),
+                ("shapes", C.POINTER(ShapeDesc)), ("bsdfs", C.POINTER(BsdfDesc)), ("textures", C.POINTER(TextureDesc)),
+                ("media", C.POINTER(MediumDesc)), ("emitters", C.POINTER(EmitterDesc)),
+                ("sensor", SensorDesc), ("film", FilmDesc), ("integrator", IntegratorDesc),
+                ("sample_count", C.c_uint32), ("sampler_seed", C.c_uint32)]
+
+
+class RenderOpts(C.Structure):
+    _fields_ = [("integrator", C.c_int32), ("max_depth", C.c_int32), ("rr_depth", C.c_int32), ("hide_emitters", C.c_int32),
+                ("spp", C.c_uint32), ("seed", C.c_uint32), ("tile_rank", C.c_uint32), ("tile_count", C.c_uint32),
+                ("device", C.c_int32), ("output_on_device", C.c_int32)]
+
+
+class RenderStats(C.Structure):
+    _fields_ = [("n_samples", C.c_uint64), ("n_iter", C.c_uint64), ("n_shadow", C.c_uint64), ("n_launches", C.c_uint64),
+                ("kernel_ms", C.c_double), ("total_ms", C.c_double)]
+
+
+class ParamGrads(C.Structure):
+    _fields_ = [("d_sigma_t", C.c_float * 3), ("d_albedo", C.c_float * 3), ("d_g", C.c_float)]
+
+
+class RaysSoA(C.Structure):
+    _fields_ = [(n, C.POINTER(C.c_float)) for n in ("ox", "oy", "oz", "dx", "dy", "dz", "tmax")]
+
+
+class HitsSoA(C.Structure):
+    _fields_ = [("t", C.POINTER(C.c_float)), ("u", C.POINTER(C.c_float)), ("v", C.POINTER(C.c_float)), ("prim", C.POINTER(C.c_uint32))]
+
+
+def make_opts(integrator=None, max_depth=None, rr_depth=None, hide_emitters=None, spp=0, seed=0,
+              tile_rank=0, tile_count=1, device=0, output_on_device=False):
+    o = RenderOpts()
+    o.integrator = -1 if integrator is None else (INTEGRATOR[integrator] if isinstance(integrator, str) else int(integrator))
+    o.max_depth = -2 if max_depth is None else int(max_depth)
+    o.rr_depth = -1 if rr_depth is None else int(rr_depth)
+    o.hide_emitters = -1 if hide_emitters is None else int(bool(hide_emitters))
+    o.spp, o.seed, o.tile_rank, o.tile_count = int(spp), int(seed) & 0xffffffff, int(tile_rank), int(tile_count)
+    o.device, o.output_on_device = int(device), int(bool(output_on_device))
+    return o
+
+
+_lib = None
+
+
+def lib():
+    """Load libliverrt.so and declare the signatures of every exported symbol."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(the hip_ad_rgb back-end has no CPU fallback)")
+    L = C.CDLL(LIB_PATH)
+    P = C.POINTER
+    L.lrt_last_error.restype = C.c_char_p
+    L.lrt_version.restype = C.c_int
+    L.lrt_scene_load_xml.argtypes = [C.c_char_p, P(C.c_char_p), C.c_int, P(C.c_void_p)]
+    L.lrt_scene_load_xml_string.argtypes = [C.c_char_p, C.c_char_p, P(C.c_char_p), C.c_int, P(C.c_void_p)]
+    L.lrt_scene_from_desc.argtypes = [P(SceneDesc), P(C.c_void_p)]
+    L.lrt_scene_desc_get.argtypes = [C.c_void_p]
+    L.lrt_scene_desc_get.restype = P(SceneDesc)
+    L.lrt_scene_free.argtypes = [C.c_void_p]
+    L.lrt_scene_free.restype = None
+    L.lrt_render.argtypes = [C.c_void_p, P(RenderOpts), C.c_void_p, C.c_void_p]
+    L.lrt_render_stats_get.argtypes = [C.c_void_p, P(RenderStats)]
+    L.lrt_film_develop.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    L.lrt_render_samples.argtypes = [C.c_void_p, P(RenderOpts), C.c_uint64, C.c_uint32, C.c_void_p]
+    L.lrt_render_backward.argtypes = [C.c_void_p, P(RenderOpts), C.c_void_p, P(ParamGrads)]
+    L.lrt_trace.argtypes = [C.c_void_p, P(RaysSoA), P(HitsSoA), C.c_uint32, C.c_int]
+    L.lrt_param_set.argtypes = [C.c_void_p, C.c_char_p, P(C.c_float), C.c_int]
+    L.lrt_param_get.argtypes = [C.c_void_p, C.c_char_p, P(C.c_float), C.c_int]
+    for name in ("lrt_scene_load_xml", "lrt_scene_load_xml_string", "lrt_scene_from_desc", "lrt_render", "lrt_render_stats_get",
+                 "lrt_film_develop", "lrt_render_samples", "lrt_render_backward", "lrt_trace", "lrt_param_set", "lrt_param_get"):
+        getattr(L, name).restype = C.c_int
+    _lib = L
+    return L
+
+
+EXPORTED_SYMBOLS = ["lrt_last_error", "lrt_version", "lrt_scene_load_xml", "lrt_scene_load_xml_string", "lrt_scene_from_desc",
+                    "lrt_scene_desc_get", "lrt_scene_free", "lrt_render", "lrt_render_stats_get", "lrt_film_develop",
+                    "lrt_render_samples", "lrt_render_backward", "lrt_trace", "lrt_param_set", "lrt_param_get"]
+
+
+def check(status):
+    if status != OK:
+        raise RuntimeError(lib().lrt_last_error().decode("utf-8", "replace"))

@@ -1,0 +1,469 @@
+// Host driver of the wavefront renderer: device scene upload, queue management,
+// kernel launches, timing.  Everything device-related lives behind this file so
+// that the rest of the library is plain host C++.
+#include "host_scene.h"
+#include "device_scene.h"
+#include "kernels.h"
+#include "bvh.h"
+#include <cmath>
+#include <cstring>
+#include <algorithm>
+#include <stdexcept>
+#include <string>
+
+namespace lrt {
+
+#define HIP_CHECK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) throw std::runtime_error(std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
+
+template <typename T> static T *dev_upload(const T *src, size_t n, hipStream_t st) {
+    T *p = nullptr; size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
+    HIP_CHECK(hipMalloc((void **) &p, bytes));
+    if (n) HIP_CHECK(hipMemcpyAsync(p, src, n * sizeof(T), hipMemcpyHostToDevice, st));
+    return p;
+}
+
+struct DeviceScene {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    DScene sc{};
+    std::vector<void *> allocs;            // everything freed in the destructor
+    // wavefront workspace
+    uint32_t capacity = 0;
+    DPathStreams q[2]{};
+    DCounters *counters = nullptr;
+    DCounters *h_counters = nullptr;       // pinned
+    float *film = nullptr; size_t film_floats = 0;
+    float *image = nullptr; size_t image_floats = 0;
+    uint32_t *pixel_list = nullptr; uint32_t pixel_list_rank = 0xffffffffu, pixel_list_count = 0, n_owned_pixels = 0;
+    std::vector<hipEvent_t> ev_pool;
+    std::vector<DMedium> h_media; DMedium *d_media = nullptr;
+
+    template <typename T> T *track(T *p) { allocs.push_back((void *) p); return p; }
+    ~DeviceScene() {
+        for (void *p : allocs) (void) hipFree(p);
+        for (auto e : ev_pool) (void) hipEventDestroy(e);
+        if (h_counters) (void) hipHostFree(h_counters);
+        if (stream) (void) hipStreamDestroy(stream);
+    }
+};
+
+void device_scene_destroy(DeviceScene *d) { delete d; }
+
+static void m4_mul(const float *a, const float *b, float *r) {
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) { float s = a[4 * i] * b[j]; for (int k = 1; k < 4; ++k) s = fmaf(a[4 * i + k], b[4 * k + j], s); r[4 * i + j] = s; }
+}
+static void m4_ident(float *m) { for (int i = 0; i < 16; ++i) m[i] = (i % 5 == 0) ? 1.f : 0.f; }
+
+// include/mitsuba/render/sensor.h:234-269 + include/mitsuba/core/transform.h:393-410:
+// sample_to_camera = inverse of (scale * translate * scale * translate * perspective), built
+// from the analytic inverses exactly as Transform::inverse_transpose composes them.
+static void build_camera(const lrt_scene_desc &d, DCamera &cam, DFilm &film) {
+    const lrt_film_desc &F = d.film; const lrt_sensor_desc &C = d.sensor;
+    float fw = (float) F.width, fh = (float) F.height;
+    float rsx = (float) F.crop_width / fw, rsy = (float) F.crop_height / fh, rox = (float) F.crop_offset_x / fw, roy = (float) F.crop_offset_y / fh;
+    float aspect = fw / fh, recip = 1.f / (C.far_clip - C.near_clip);
+    float tn = (float) tan((double) (C.fov_x * .5f) * (3.14159265358979323846 / 180.0));
+    (void) recip;
+    float S1i[16], T1i[16], S2i[16], T2i[16], Pit[16], t0[16], t1[16], t2[16], it[16];
+    m4_ident(S1i); S1i[0] = 1.f / (1.f / rsx); S1i[5] = 1.f / (1.f / rsy); S1i[10] = 1.f / 1.f;
+    m4_ident(T1i); T1i[12] = rox; T1i[13] = roy; T1i[14] = -0.f;
+    m4_ident(S2i); S2i[0] = 1.f / -0.5f; S2i[5] = 1.f / (-0.5f * aspect); S2i[10] = 1.f;
+    m4_ident(T2i); T2i[12] = 1.f; T2i[13] = 1.f / aspect; T2i[14] = -0.f;
+    // inverse of the perspective matrix, transposed
+    float Pinv[16]; m4_ident(Pinv); Pinv[0] = tn; Pinv[5] = tn; Pinv[10] = 0.f; Pinv[15] = 1.f / C.near_clip; Pinv[11] = 1.f;
+    Pinv[14] = (C.near_clip - C.far_clip) / (C.far_clip * C.near_clip);
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) Pit[4 * i + j] = Pinv[4 * j + i];
+    m4_mul(S1i, T1i, t0); m4_mul(t0, S2i, t1); m4_mul(t1, T2i, t2); m4_mul(t2, Pit, it);
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) cam.s2c[4 * i + j] = it[4 * j + i];
+    memcpy(cam.to_world, C.to_world, sizeof(float) * 12);
+    cam.near_clip = C.near_clip; cam.far_clip = C.far_clip; cam.medium = C.medium;
+
+    film.width = F.crop_width; film.height = F.crop_height; film.crop_offset_x = F.crop_offset_x; film.crop_offset_y = F.crop_offset_y;
+    film.scale_x = 1.f / (float) F.crop_width; film.scale_y = 1.f / (float) F.crop_height;
+    film.offset_x = -(float) F.crop_offset_x * film.scale_x; film.offset_y = -(float) F.crop_offset_y * film.scale_y;
+    film.has_alpha = F.has_alpha; film.channels = F.has_alpha ? 5 : 4; film.rfilter = F.rfilter;
+    film.rf_radius = 0.5f; film.rf_inv_radius = 1.f;
+    if (F.rfilter == LRT_RFILTER_GAUSSIAN) {             // src/rfilters/gaussian.cpp:52-95
+        float stddev = F.rfilter_param; film.rf_radius = 4.f * stddev;
+        static const double coeff[10] = { 9.992604880e-1, -4.977025247e-1, 1.222248550e-1, -1.932406282e-2, 2.136713061e-3,
+                                          -1.679873860e-4, 9.202145248e-6, -3.329417433e-7, 7.128382794e-9, -6.821193280e-11 };
+        double sc = 1; for (int i = 0; i < 10; ++i) { film.rf_coeff[i] = (float) (coeff[i] * sc); sc /= (double) stddev * (double) stddev; }
+        float x = film.rf_radius * film.rf_radius, x2 = x * x, x4 = x2 * x2, x8 = x4 * x4; const float *c = film.rf_coeff;
+        float a0 = fmaf(x, c[1], c[0]), a1 = fmaf(x, c[3], c[2]), a2 = fmaf(x, c[5], c[4]), a3 = fmaf(x, c[7], c[6]), a4 = fmaf(x, c[9], c[8]);
+        float b0 = fmaf(x2, a1, a0), b1 = fmaf(x2, a3, a2), c0 = fmaf(x4, b1, b0);
+        film.rf_coeff[0] -= fmaf(x8, a4, c0);
+    } else if (F.rfilter == LRT_RFILTER_TENT) { film.rf_radius = F.rfilter_param; film.rf_inv_radius = 1.f / film.rf_radius; }
+    film.fn = (int) ceilf(film.rf_radius - .5f); film.fcount = 2 * film.fn + 1;
+}
+
+static void inverse3(const float *m16, float *out9) {    // double-precision inverse of the linear part
+    double m[3][3]; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) m[i][j] = m16[4 * i + j];
+    double det = m[0][0] * (m[1][1] * m[2][2] - m[1][2] * m[2][1]) - m[0][1] * (m[1][0] * m[2][2] - m[1][2] * m[2][0]) + m[0][2] * (m[1][0] * m[2][1] - m[1][1] * m[2][0]);
+    double id = 1.0 / det;
+    out9[0] = (float) ((m[1][1] * m[2][2] - m[1][2] * m[2][1]) * id); out9[1] = (float) ((m[0][2] * m[2][1] - m[0][1] * m[2][2]) * id); out9[2] = (float) ((m[0][1] * m[1][2] - m[0][2] * m[1][1]) * id);
+    out9[3] = (float) ((m[1][2] * m[2][0] - m[1][0] * m[2][2]) * id); out9[4] = (float) ((m[0][0] * m[2][2] - m[0][2] * m[2][0]) * id); out9[5] = (float) ((m[0][2] * m[1][0] - m[0][0] * m[1][2]) * id);
+    out9[6] = (float) ((m[1][0] * m[2][1] - m[1][1] * m[2][0]) * id); out9[7] = (float) ((m[0][1] * m[2][0] - m[0][0] * m[2][1]) * id); out9[8] = (float) ((m[0][0] * m[1][1] - m[0][1] * m[1][0]) * id);
+}
+
+static uint32_t log2i_ceil(uint32_t v) { uint32_t r = 0; while ((1u << r) < v) ++r; return r; }
+
+// include/mitsuba/core/distr_2d.h:403-510 (normalised, single slice); levels are
+// concatenated with 16-byte aligned offsets so that a 2x2 patch is one float4 load.
+static void build_hierarchy(const std::vector<float> &lum, uint32_t w, uint32_t h, DEnv &E, std::vector<float> &out) {
+    uint32_t npx = w - 1, npy = h - 1;
+    E.patch_size[0] = 1.f / (float) npx; E.patch_size[1] = 1.f / (float) npy;
+    E.inv_patch_size[0] = (float) npx; E.inv_patch_size[1] = (float) npy;
+    E.max_patch[0] = npx - 1; E.max_patch[1] = npy - 1;
+    uint32_t max_level = log2i_ceil(std::max(npx, npy));
+    struct L { uint32_t w, h, off; };
+    std::vector<L> lv; uint32_t total = 0;
+    auto add = [&](uint32_t lw, uint32_t lh) { lv.push_back({ lw, lh, total }); total += (lw * lh + 3u) & ~3u; };
+    add(w, h);
+    uint32_t lx = npx, ly = npy;
+    for (int level = (int) max_level; level >= 0; --level) { lx += lx & 1u; ly += ly & 1u; add(lx, ly); lx >>= 1; ly >>= 1; }
+    if (lv.size() > LRT_MAX_HIER_LEVELS) throw std::runtime_error("environment map too large for the sampling hierarchy");
+    out.assign(total, 0.f);
+    auto index = [](uint32_t x, uint32_t y, uint32_t width) { return ((x & 1u) | (((x & ~1u) | (y & 1u)) << 1)) + ((y & ~1u) * width); };
+    float *l0 = &out[lv[0].off], *l1 = &out[lv[1].off];
+    const float *in = lum.data(); double sum = 0.0;
+    for (uint32_t y = 0; y < npy; ++y) { for (uint32_t x = 0; x < npx; ++x) { float avg = .25f * (in[0] + in[1] + in[w] + in[w + 1]); sum += (double) avg; l1[index(x, y, lv[1].w)] = avg; ++in; } ++in; }
+    float scale = (float) ((double) (npx * npy) / sum);
+    for (uint32_t i = 0; i < w * h; ++i) l0[i] = lum[i] * scale;
+    for (uint32_t i = 0; i < lv[1].w * lv[1].h; ++i) l1[i] *= scale;
+    lx = npx; ly = npy;
+    for (uint32_t level = 2; level <= max_level + 1; ++level) {
+        const float *a = &out[lv[level - 1].off]; float *b = &out[lv[level].off];
+        lx = (lx + 1u) >> 1; ly = (ly + 1u) >> 1;
+        for (uint32_t y = 0; y < ly; ++y) for (uint32_t x = 0; x < lx; ++x) { const float *d0 = a + index(x * 2, y * 2, lv[level - 1].w); b[index(x, y, lv[level].w)] = d0[0] + d0[1] + d0[2] + d0[3]; }
+    }
+    E.n_levels = (int) lv.size();
+    for (size_t i = 0; i < lv.size(); ++i) { E.level_offset[i] = lv[i].off; E.level_width[i] = lv[i].w; }
+}
+
+static void upload_media(DeviceScene *D, const lrt_scene_desc &d) {
+    D->h_media.resize(std::max<uint32_t>(d.n_media, 1));
+    for (uint32_t i = 0; i < d.n_media; ++i) {
+        const lrt_medium_desc &M = d.media[i]; DMedium &o = D->h_media[i];
+        for (int k = 0; k < 3; ++k) { o.sigma_t[k] = M.sigma_t[k] * M.scale; o.albedo[k] = M.albedo[k]; }   // homogeneous.cpp:121-126 eval_sigmat
+        o.has_spectral_extinction = M.has_spectral_extinction; o.sample_emitters = M.sample_emitters; o.phase = M.phase; o.g = M.g;
+    }
+    HIP_CHECK(hipMemcpyAsync(D->d_media, D->h_media.data(), D->h_media.size() * sizeof(DMedium), hipMemcpyHostToDevice, D->stream));
+}
+
+DeviceScene *device_scene_create(const lrt_scene_desc &d, int device) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count == 0)
+        throw std::runtime_error("no HIP device available: the hip_ad_rgb back-end has no CPU fallback");
+    if (device < 0 || device >= count) throw std::runtime_error("invalid HIP device ordinal " + std::to_string(device));
+    HIP_CHECK(hipSetDevice(device));
+    std::unique_ptr<DeviceScene> D(new DeviceScene());
+    D->device = device;
+    HIP_CHECK(hipStreamCreateWithFlags(&D->stream, hipStreamNonBlocking));
+    hipStream_t st = D->stream;
+    DScene &sc = D->sc;
+    // ---- acceleration structure
+    HostBVH bvh; build_bvh(d.positions, d.faces, d.n_faces, bvh);
+    sc.nodes = (const float4 *) D->track(dev_upload(bvh.nodes.data(), bvh.nodes.size(), st));
+    sc.tris = (const float4 *) D->track(dev_upload(bvh.tris.data(), bvh.tris.size(), st));
+    sc.root_is_leaf = bvh.root_is_leaf; sc.root_leaf_first = bvh.root_first; sc.root_leaf_count = bvh.root_count;
+    sc.n_faces = d.n_faces; sc.n_emitters = d.n_emitters;
+    // ---- geometry attributes
+    sc.positions = D->track(dev_upload(d.positions, 3 * (size_t) d.n_vertices, st));
+    sc.normals = D->track(dev_upload(d.normals, 3 * (size_t) d.n_vertices, st));
+    sc.texcoords = D->track(dev_upload(d.texcoords, 2 * (size_t) d.n_vertices, st));
+    sc.faces = D->track(dev_upload(d.faces, 3 * (size_t) d.n_faces, st));
+    sc.face_shape = D->track(dev_upload(d.face_shape, d.n_faces, st));
+    std::vector<DShape> shapes(d.n_shapes);
+    for (uint32_t i = 0; i < d.n_shapes; ++i) { const lrt_shape_desc &s = d.shapes[i]; shapes[i] = { s.bsdf, s.emitter, s.interior_medium, s.exterior_medium, s.has_normals, s.has_texcoords, s.flip_normals, s.kind }; }
+    sc.shapes = D->track(dev_upload(shapes.data(), shapes.size(), st));
+    // ---- textures (bitmaps: one luminance float per texel, src/textures/bitmap.cpp:540-552)
+    std::vector<DTexture> tex(d.n_textures); std::vector<float> tex_data;
+    for (uint32_t i = 0; i < d.n_textures; ++i) {
+        const lrt_texture_desc &T = d.textures[i]; DTexture &o = tex[i]; memset(&o, 0, sizeof(o));
+        o.type = T.type; o.width = T.width; o.height = T.height; o.channels = T.channels;
+        for (int k = 0; k < 3; ++k) { o.color0[k] = T.color0[k]; o.color1[k] = T.color1[k]; }
+        for (int k = 0; k < 6; ++k) o.to_uv[k] = T.to_uv[k];
+        if (T.type == LRT_TEX_BITMAP) {
+            o.data_offset = (uint32_t) tex_data.size();
+            size_t np = (size_t) T.width * T.height;
+            for (size_t p = 0; p < np; ++p) {
+                const float *px = T.data + p * T.channels;
+                tex_data.push_back(T.channels == 1 ? px[0] : px[0] * 0.212671f + px[1] * 0.715160f + px[2] * 0.072169f);
+            }
+        }
+    }
+    sc.textures = D->track(dev_upload(tex.data(), tex.size(), st));
+    sc.tex_data = D->track(dev_upload(tex_data.data(), tex_data.size(), st));
+    // ---- BSDFs
+    std::vector<DBsdf> bsdfs(d.n_bsdfs); sc.has_null_bsdf = 0;
+    auto leaf_flags = [](int type) { return type == LRT_BSDF_DIFFUSE ? F_SMOOTH : type == LRT_BSDF_DIELECTRIC ? F_DELTA : F_NULL; };
+    for (uint32_t i = 0; i < d.n_bsdfs; ++i) {
+        const lrt_bsdf_desc &B = d.bsdfs[i];
+        bsdfs[i] = { B.type, B.reflectance, B.nested, B.texture, B.eta, B.scale, 0, 0 };
+        if (B.type == LRT_BSDF_BUMPMAP) {
+            if (B.nested < 0 || (uint32_t) B.nested >= d.n_bsdfs || d.bsdfs[B.nested].type == LRT_BSDF_BUMPMAP) throw std::runtime_error("bumpmap: invalid nested BSDF");
+            bsdfs[i].flags = leaf_flags(d.bsdfs[B.nested].type);
+        } else bsdfs[i].flags = leaf_flags(B.type);
+        if (B.type == LRT_BSDF_NULL) sc.has_null_bsdf = 1;
+    }
+    sc.bsdfs = D->track(dev_upload(bsdfs.data(), bsdfs.size(), st));
+    // ---- media
+    HIP_CHECK(hipMalloc((void **) &D->d_media, std::max<uint32_t>(d.n_media, 1) * sizeof(DMedium))); D->track(D->d_media);
+    upload_media(D.get(), d); sc.media = D->d_media;
+    // ---- bounds (src/render/scene.cpp:49; include/mitsuba/core/bbox.h:343-346; envmap.cpp:337-351)
+    DEnv &E = sc.env; memset(&E, 0, sizeof(E)); E.type = -1; E.emitter = -1;
+    {
+        float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
+        for (uint32_t i = 0; i < d.n_vertices; ++i) for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], d.positions[3 * i + a]); hi[a] = fmaxf(hi[a], d.positions[3 * i + a]); }
+        const float ray_eps = 5.9604644775390625e-8f * 1500.f;
+        if (d.n_vertices) {
+            float c[3], dd[3]; for (int a = 0; a < 3; ++a) { c[a] = (hi[a] + lo[a]) * 0.5f; dd[a] = c[a] - hi[a]; E.bsphere_c[a] = c[a]; }
+            float r = sqrtf(fmaf(dd[2], dd[2], fmaf(dd[1], dd[1], dd[0] * dd[0])));
+            E.bsphere_r = fmaxf(ray_eps, r * (1.f + ray_eps));
+        } else { E.bsphere_c[0] = E.bsphere_c[1] = E.bsphere_c[2] = 0.f; E.bsphere_r = ray_eps; }
+    }
+    // ---- emitters
+    std::vector<DEmitter> em(d.n_emitters); std::vector<float> env_rgbx, hier;
+    for (uint32_t i = 0; i < d.n_emitters; ++i) {
+        const lrt_emitter_desc &S = d.emitters[i]; DEmitter &o = em[i]; memset(&o, 0, sizeof(o));
+        o.type = S.type; o.shape = S.shape; o.scale = S.scale; for (int k = 0; k < 3; ++k) o.radiance[k] = S.radiance[k];
+        if (S.type == LRT_EMITTER_AREA) {
+            const lrt_shape_desc &sd = d.shapes[S.shape];
+            if (sd.kind != LRT_SHAPE_RECTANGLE) throw std::runtime_error("area emitters are supported on rectangle shapes only");
+            memcpy(o.to_world, sd.to_world, sizeof(float) * 12);
+            auto xv = [&](float x, float y, float z, float *r) { const float *m = sd.to_world; for (int a = 0; a < 3; ++a) r[a] = fmaf(m[4 * a + 2], z, fmaf(m[4 * a + 1], y, m[4 * a] * x)); };
+            float du[3], dv[3]; xv(2.f, 0.f, 0.f, du); xv(0.f, 2.f, 0.f, dv);
+            float cx = fmaf(du[1], dv[2], -(du[2] * dv[1])), cy = fmaf(du[2], dv[0], -(du[0] * dv[2])), cz = fmaf(du[0], dv[1], -(du[1] * dv[0]));
+            o.inv_area = 1.f / sqrtf(fmaf(cz, cz, fmaf(cy, cy, cx * cx)));
+            uint32_t v0 = d.faces[3 * sd.first_face];
+            for (int a = 0; a < 3; ++a) o.n[a] = sd.flip_normals ? -d.normals[3 * v0 + a] : d.normals[3 * v0 + a];
+        } else {
+            E.type = S.type; E.emitter = (int) i; E.scale = S.scale; for (int k = 0; k < 3; ++k) E.radiance[k] = S.radiance[k];
+            if (S.type == LRT_EMITTER_ENVMAP) {             // src/emitters/envmap.cpp:139-236
+                uint32_t w = (uint32_t) S.width, h = (uint32_t) S.height; E.w = w + 1; E.h = h;
+                env_rgbx.assign((size_t) E.w * h * 4, 0.f); std::vector<float> lum((size_t) E.w * h);
+                float theta_scale = 1.f / (float) (h - 1) * 3.14159265358979323846f;
+                const float *in = S.data;
+                for (uint32_t y = 0; y < h; ++y) {
+                    float sin_theta = (float) sin((double) ((float) y * theta_scale));
+                    for (uint32_t x = 0; x < w; ++x) {
+                        float l = fmaxf((in[0] * 0.212671f + in[1] * 0.715160f + in[2] * 0.072169f) - 0.f, 0.f);
+                        lum[(size_t) y * E.w + x] = l * sin_theta;
+                        float *o4 = &env_rgbx[((size_t) y * E.w + x) * 4]; o4[0] = in[0]; o4[1] = in[1]; o4[2] = in[2];
+                        in += 3;
+                    }
+                    lum[(size_t) y * E.w + w] = lum[(size_t) y * E.w];
+                    for (int k = 0; k < 3; ++k) env_rgbx[((size_t) y * E.w + w) * 4 + k] = env_rgbx[((size_t) y * E.w) * 4 + k];
+                }
+                build_hierarchy(lum, E.w, h, E, hier);
+                for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) E.to_world[3 * a + b] = S.to_world[4 * a + b];
+                inverse3(S.to_world, E.to_local);
+            }
+        }
+    }
+    sc.emitters = D->track(dev_upload(em.data(), em.size(), st));
+    sc.env_data = (const float4 *) D->track(dev_upload(env_rgbx.data(), env_rgbx.size(), st));
+    sc.env_hier = D->track(dev_upload(hier.data(), hier.size(), st));
+    build_camera(d, sc.cam, sc.film);
+    HIP_CHECK(hipMalloc((void **) &D->counters, sizeof(DCounters))); D->track(D->counters);
+    HIP_CHECK(hipHostMalloc((void **) &D->h_counters, sizeof(DCounters)));
+    HIP_CHECK(hipStreamSynchronize(st));
+    return D.release();
+}
+
+void device_scene_update_params(DeviceScene *D, const lrt_scene_desc &d) {
+    HIP_CHECK(hipSetDevice(D->device));
+    upload_media(D, d);
+    HIP_CHECK(hipStreamSynchronize(D->stream));
+}
+
+static void ensure_workspace(DeviceScene *D, uint32_t capacity) {
+    if (D->capacity >= capacity) return;
+    auto alloc_q = [&](DPathStreams &q) {
+        HIP_CHECK(hipMalloc((void **) &q.o_maxt, (size_t) capacity * 16)); D->track(q.o_maxt);
+        HIP_CHECK(hipMalloc((void **) &q.d_eta, (size_t) capacity * 16)); D->track(q.d_eta);
+        HIP_CHECK(hipMalloc((void **) &q.tp_pdf, (size_t) capacity * 16)); D->track(q.tp_pdf);
+        HIP_CHECK(hipMalloc((void **) &q.res_flags, (size_t) capacity * 16)); D->track(q.res_flags);
+        HIP_CHECK(hipMalloc((void **) &q.lp_lane, (size_t) capacity * 16)); D->track(q.lp_lane);
+        HIP_CHECK(hipMalloc((void **) &q.rng, (size_t) capacity * 8)); D->track(q.rng);
+    };
+    alloc_q(D->q[0]); alloc_q(D->q[1]);    // (older, smaller streams stay tracked and are freed with the scene)
+    D->capacity = capacity;
+}
+
+static hipEvent_t get_event(DeviceScene *D, size_t i) {
+    while (D->ev_pool.size() <= i) { hipEvent_t e; HIP_CHECK(hipEventCreate(&e)); D->ev_pool.push_back(e); }
+    return D->ev_pool[i];
+}
+
+struct ResolvedOpts { int integrator, max_depth, rr_depth, hide_emitters; uint32_t spp, seed, tile_rank, tile_count; };
+static ResolvedOpts resolve(const lrt_scene_desc &d, const lrt_render_opts *o) {
+    ResolvedOpts r;
+    r.integrator = (o && o->integrator >= 0) ? o->integrator : d.integrator.type;
+    if (r.integrator == LRT_INTEGRATOR_PRBVOLPATH) r.integrator = LRT_INTEGRATOR_VOLPATH;
+    r.max_depth = (o && o->max_depth != -2) ? o->max_depth : d.integrator.max_depth;
+    r.rr_depth = (o && o->rr_depth >= 0) ? o->rr_depth : d.integrator.rr_depth;
+    r.hide_emitters = (o && o->hide_emitters >= 0) ? (o->hide_emitters != 0) : (d.integrator.hide_emitters != 0);
+    r.spp = (o && o->spp) ? o->spp : d.sample_count;
+    r.seed = o ? o->seed : 0;
+    r.tile_rank = o ? o->tile_rank : 0; r.tile_count = (o && o->tile_count) ? o->tile_count : 1;
+    if (r.tile_rank >= r.tile_count) throw std::runtime_error("tile_rank must be smaller than tile_count");
+    if (r.spp == 0) throw std::runtime_error("spp must be positive");
+    return r;
+}
+
+// 32x32 pixel tiles in row-major tile order, tile k -> rank k % tile_count
+static void ensure_pixel_list(DeviceScene *D, const ResolvedOpts &O) {
+    const DFilm &F = D->sc.film;
+    if (O.tile_count == 1) { D->n_owned_pixels = (uint32_t) F.width * F.height; return; }
+    if (D->pixel_list && D->pixel_list_rank == O.tile_rank && D->pixel_list_count == O.tile_count) return;
+    std::vector<uint32_t> px;
+    uint32_t tx = (F.width + 31) / 32, ty = (F.height + 31) / 32;
+    for (uint32_t t = O.tile_rank; t < tx * ty; t += O.tile_count) {
+        uint32_t x0 = (t % tx) * 32, y0 = (t / tx) * 32;
+        for (uint32_t y = y0; y < std::min<uint32_t>(y0 + 32, F.height); ++y)
+            for (uint32_t x = x0; x < std::min<uint32_t>(x0 + 32, F.width); ++x) px.push_back(y * F.width + x);
+    }
+    D->pixel_list = D->track(dev_upload(px.data(), px.size(), D->stream));
+    D->pixel_list_rank = O.tile_rank; D->pixel_list_count = O.tile_count; D->n_owned_pixels = (uint32_t) px.size();
+}
+
+// The wavefront loop.  sample_out != nullptr: per-lane test hook for lanes [lane_begin, lane_begin + n_lanes).
+static void run_wavefront(DeviceScene *D, const lrt_scene_desc &d, const ResolvedOpts &O, uint64_t lane_begin, uint64_t n_lanes,
+                          const uint32_t *pixel_list, float *film, float *sample_out, lrt_render_stats &stats) {
+    hipStream_t st = D->stream;
+    DRenderParams rp{};
+    rp.integrator = O.integrator; rp.max_depth = O.max_depth; rp.rr_depth = O.rr_depth; rp.hide_emitters = O.hide_emitters;
+    rp.spp = O.spp; rp.log2_spp = ((O.spp & (O.spp - 1)) == 0) ? (uint32_t) __builtin_ctz(O.spp) : 0xffffffffu;
+    rp.seed_value = d.sampler_seed + O.seed; rp.tile_rank = O.tile_rank; rp.tile_count = O.tile_count; rp.n_lanes = n_lanes;
+    const uint32_t chunk = (uint32_t) std::min<uint64_t>(n_lanes, 1u << 23);
+    ensure_workspace(D, std::max<uint32_t>(chunk, 1));
+    HIP_CHECK(hipMemsetAsync(D->counters, 0, sizeof(DCounters), st));
+    size_t ev = 0;
+    hipEvent_t e_begin = get_event(D, ev++), e_end = get_event(D, ev++);
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> launches;
+    HIP_CHECK(hipEventRecord(e_begin, st));
+    uint64_t n_iter = 0;
+    for (uint64_t base = 0; base < n_lanes; base += chunk) {
+        uint32_t n = (uint32_t) std::min<uint64_t>(chunk, n_lanes - base);
+        k_raygen<<<(n + LRT_BLOCK - 1) / LRT_BLOCK, LRT_BLOCK, 0, st>>>(D->sc, rp, D->q[0], pixel_list, lane_begin + base, n, 0);
+        int cur = 0;
+        while (n > 0) {
+            HIP_CHECK(hipMemsetAsync(&D->counters->n_out, 0, sizeof(uint32_t), st));
+            hipEvent_t a = get_event(D, ev++), b = get_event(D, ev++);
+            HIP_CHECK(hipEventRecord(a, st));
+            uint32_t grid = (n + LRT_BLOCK - 1) / LRT_BLOCK;
+            if (O.integrator == LRT_INTEGRATOR_PATH)
+                k_iterate<LRT_INTEGRATOR_PATH><<<grid, LRT_BLOCK, 0, st>>>(D->sc, rp, D->q[cur], D->q[cur ^ 1], D->counters, n, film, sample_out, lane_begin);
+            else
+                k_iterate<LRT_INTEGRATOR_VOLPATH><<<grid, LRT_BLOCK, 0, st>>>(D->sc, rp, D->q[cur], D->q[cur ^ 1], D->counters, n, film, sample_out, lane_begin);
+            HIP_CHECK(hipEventRecord(b, st));
+            launches.emplace_back(a, b);
+            HIP_CHECK(hipMemcpyAsync(D->h_counters, D->counters, sizeof(DCounters), hipMemcpyDeviceToHost, st));
+            HIP_CHECK(hipStreamSynchronize(st));
+            n_iter += n;
+            n = D->h_counters->n_out;
+            cur ^= 1;
+        }
+    }
+    HIP_CHECK(hipEventRecord(e_end, st));
+    HIP_CHECK(hipMemcpyAsync(D->h_counters, D->counters, sizeof(DCounters), hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    HIP_CHECK(hipGetLastError());
+    stats.n_samples = n_lanes; stats.n_iter = n_iter; stats.n_shadow = D->h_counters->n_shadow; stats.n_launches = launches.size();
+    float ms = 0.f; double ksum = 0.0;
+    for (auto &l : launches) { HIP_CHECK(hipEventElapsedTime(&ms, l.first, l.second)); ksum += ms; }
+    stats.kernel_ms = ksum;
+    HIP_CHECK(hipEventElapsedTime(&ms, e_begin, e_end)); stats.total_ms = ms;
+}
+
+void device_render(DeviceScene *D, const lrt_scene_desc &d, const lrt_render_opts *opts, float *film_raw, float *image, lrt_render_stats &stats) {
+    HIP_CHECK(hipSetDevice(D->device));
+    ResolvedOpts O = resolve(d, opts);
+    const DFilm &F = D->sc.film;
+    bool on_device = opts && opts->output_on_device;
+    size_t np = (size_t) F.width * F.height, film_floats = np * F.channels, image_floats = np * (F.has_alpha ? 4 : 3);
+    ensure_pixel_list(D, O);
+    uint64_t n_lanes = (uint64_t) D->n_owned_pixels * O.spp;
+    if ((uint64_t) np * O.spp > 0xffffffffull) throw std::runtime_error("more than 2^32 samples per render: split into passes (src/render/integrator.cpp:279-293)");
+    float *film = nullptr;
+    if (on_device && film_raw) film = film_raw;
+    else { if (D->film_floats < film_floats) { HIP_CHECK(hipMalloc((void **) &D->film, film_floats * 4)); D->track(D->film); D->film_floats = film_floats; } film = D->film; }
+    HIP_CHECK(hipMemsetAsync(film, 0, film_floats * 4, D->stream));
+    run_wavefront(D, d, O, 0, n_lanes, O.tile_count > 1 ? D->pixel_list : nullptr, film, nullptr, stats);
+    if (image) {
+        float *img = image;
+        if (!on_device) { if (D->image_floats < image_floats) { HIP_CHECK(hipMalloc((void **) &D->image, image_floats * 4)); D->track(D->image); D->image_floats = image_floats; } img = D->image; }
+        k_develop<<<(uint32_t) ((np + 255) / 256), 256, 0, D->stream>>>(F, film, img, (uint32_t) np);
+        if (!on_device) HIP_CHECK(hipMemcpyAsync(image, img, image_floats * 4, hipMemcpyDeviceToHost, D->stream));
+    }
+    if (film_raw && !on_device) HIP_CHECK(hipMemcpyAsync(film_raw, film, film_floats * 4, hipMemcpyDeviceToHost, D->stream));
+    HIP_CHECK(hipStreamSynchronize(D->stream));
+    HIP_CHECK(hipGetLastError());
+}
+
+void device_develop(DeviceScene *D, const float *film_raw, float *image, int on_device) {
+    HIP_CHECK(hipSetDevice(D->device));
+    const DFilm &F = D->sc.film;
+    size_t np = (size_t) F.width * F.height, film_floats = np * F.channels, image_floats = np * (F.has_alpha ? 4 : 3);
+    const float *film = film_raw; float *img = image;
+    if (!on_device) {
+        if (D->film_floats < film_floats) { HIP_CHECK(hipMalloc((void **) &D->film, film_floats * 4)); D->track(D->film); D->film_floats = film_floats; }
+        if (D->image_floats < image_floats) { HIP_CHECK(hipMalloc((void **) &D->image, image_floats * 4)); D->track(D->image); D->image_floats = image_floats; }
+        HIP_CHECK(hipMemcpyAsync(D->film, film_raw, film_floats * 4, hipMemcpyHostToDevice, D->stream));
+        film = D->film; img = D->image;
+    }
+    k_develop<<<(uint32_t) ((np + 255) / 256), 256, 0, D->stream>>>(F, film, img, (uint32_t) np);
+    if (!on_device) HIP_CHECK(hipMemcpyAsync(image, img, image_floats * 4, hipMemcpyDeviceToHost, D->stream));
+    HIP_CHECK(hipStreamSynchronize(D->stream));
+    HIP_CHECK(hipGetLastError());
+}
+
+void device_render_samples(DeviceScene *D, const lrt_scene_desc &d, const lrt_render_opts *opts, uint64_t lane_begin, uint32_t n, float *out, lrt_render_stats &stats) {
+    HIP_CHECK(hipSetDevice(D->device));
+    ResolvedOpts O = resolve(d, opts);
+    if (lane_begin + n > 0x100000000ull) throw std::runtime_error("lane range exceeds 2^32");
+    float *d_out = nullptr;
+    HIP_CHECK(hipMalloc((void **) &d_out, (size_t) std::max<uint32_t>(n, 1) * 16));
+    try {
+        HIP_CHECK(hipMemsetAsync(d_out, 0, (size_t) n * 16, D->stream));
+        run_wavefront(D, d, O, lane_begin, n, nullptr, nullptr, d_out, stats);
+        HIP_CHECK(hipMemcpyAsync(out, d_out, (size_t) n * 16, hipMemcpyDeviceToHost, D->stream));
+        HIP_CHECK(hipStreamSynchronize(D->stream));
+    } catch (...) { (void) hipFree(d_out); throw; }
+    HIP_CHECK(hipFree(d_out));
+}
+
+void device_trace(DeviceScene *D, const lrt_rays_soa *rays, const lrt_hits_soa *hits, uint32_t n, int any_hit) {
+    HIP_CHECK(hipSetDevice(D->device));
+    hipStream_t st = D->stream;
+    std::vector<void *> tmp;
+    auto up = [&](const float *h) { float *p; HIP_CHECK(hipMalloc((void **) &p, (size_t) std::max<uint32_t>(n, 1) * 4)); tmp.push_back(p); HIP_CHECK(hipMemcpyAsync(p, h, (size_t) n * 4, hipMemcpyHostToDevice, st)); return p; };
+    auto mk = [&]() { float *p; HIP_CHECK(hipMalloc((void **) &p, (size_t) std::max<uint32_t>(n, 1) * 4)); tmp.push_back(p); return p; };
+    try {
+        float *ox = up(rays->ox), *oy = up(rays->oy), *oz = up(rays->oz), *dx = up(rays->dx), *dy = up(rays->dy), *dz = up(rays->dz), *tm = up(rays->tmax);
+        float *t = mk(), *u = mk(), *v = mk(); uint32_t *prim = (uint32_t *) mk();
+        uint32_t grid = (n + LRT_BLOCK - 1) / LRT_BLOCK;
+        if (n) {
+            if (any_hit) k_trace<true><<<grid, LRT_BLOCK, 0, st>>>(D->sc, ox, oy, oz, dx, dy, dz, tm, t, u, v, prim, n);
+            else k_trace<false><<<grid, LRT_BLOCK, 0, st>>>(D->sc, ox, oy, oz, dx, dy, dz, tm, t, u, v, prim, n);
+        }
+        HIP_CHECK(hipMemcpyAsync(hits->t, t, (size_t) n * 4, hipMemcpyDeviceToHost, st));
+        if (!any_hit) {
+            if (hits->u) HIP_CHECK(hipMemcpyAsync(hits->u, u, (size_t) n * 4, hipMemcpyDeviceToHost, st));
+            if (hits->v) HIP_CHECK(hipMemcpyAsync(hits->v, v, (size_t) n * 4, hipMemcpyDeviceToHost, st));
+            if (hits->prim) HIP_CHECK(hipMemcpyAsync(hits->prim, prim, (size_t) n * 4, hipMemcpyDeviceToHost, st));
+        }
+        HIP_CHECK(hipStreamSynchronize(st));
+        HIP_CHECK(hipGetLastError());
+    } catch (...) { for (void *p : tmp) (void) hipFree(p); throw; }
+    for (void *p : tmp) (void) hipFree(p);
+}
+
+} // namespace lrt
+
+namespace lrt {
+void device_render_backward(DeviceScene *, const lrt_scene_desc &, const lrt_render_opts *, const float *, lrt_param_grads *) {
+    throw std::runtime_error("render_backward: not supported yet");
+}
+}

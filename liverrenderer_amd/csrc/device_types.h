@@ -1,0 +1,126 @@
+// POD structures shared by the host driver (render.cpp side of device.hip) and
+// the gfx950 kernels.  Uniform scene data is passed to kernels BY VALUE
+// (kernarg segment -> scalar loads), bulk data by pointer.
+#pragma once
+#include <stdint.h>
+#include <hip/hip_vector_types.h>
+
+namespace lrt {
+
+struct DShape {
+    int32_t bsdf, emitter, interior_medium, exterior_medium;
+    int32_t has_normals, has_texcoords, flip_normals, kind;
+};
+
+struct DBsdf {
+    int32_t type, reflectance, nested, texture;
+    float eta, scale; int32_t flags, pad;
+};
+
+struct DTexture {
+    int32_t type, width, height, channels;
+    float color0[3]; float color1[3];
+    float to_uv[6];            // first two rows of the 3x3 uv transform
+    uint32_t data_offset;      // into tex_data (floats); bitmap: 1 float per texel (luminance or Y)
+    uint32_t pad;
+};
+
+struct DMedium {
+    float sigma_t[3]; float albedo[3];   // sigma_t already multiplied by scale
+    int32_t has_spectral_extinction, sample_emitters, phase; float g;
+};
+
+struct DEmitter {
+    int32_t type, shape; float radiance[3]; float scale;
+    float n[3]; float inv_area;          // area: rectangle frame normal (flip applied), 1/area
+    float to_world[12];                  // area: rectangle to_world rows 0..2
+};
+
+#define LRT_MAX_HIER_LEVELS 16
+
+struct DCamera {
+    float s2c[16];             // sample_to_camera, row-major, projective
+    float to_world[12];        // rows 0..2
+    float near_clip, far_clip;
+    int32_t medium, pad;
+};
+
+struct DFilm {
+    int32_t width, height;               // crop size
+    int32_t crop_offset_x, crop_offset_y;
+    float scale_x, scale_y, offset_x, offset_y;   // render_sample(): adjusted = fmadd(pos, scale, offset)
+    int32_t channels, has_alpha, rfilter, fcount; // fcount = 2*ceil(radius-.5)+1
+    float rf_radius, rf_inv_radius; int32_t fn, pad;
+    float rf_coeff[10];
+    int32_t pad2[2];
+};
+
+struct DEnv {
+    int32_t type;              // -1: none, LRT_EMITTER_ENVMAP, LRT_EMITTER_CONSTANT
+    int32_t emitter;           // emitter index
+    uint32_t w, h;             // (w+1) x h storage
+    float scale;
+    float bsphere_c[3]; float bsphere_r;
+    float to_world[9];         // rotation part rows
+    float to_local[9];
+    float patch_size[2], inv_patch_size[2];
+    uint32_t max_patch[2];
+    int32_t n_levels;
+    uint32_t level_offset[LRT_MAX_HIER_LEVELS];   // into env_hier (floats)
+    uint32_t level_width[LRT_MAX_HIER_LEVELS];
+    float radiance[3];         // constant emitter
+};
+
+struct DScene {
+    // acceleration structure
+    const float4 *nodes;       // 4 x float4 per BVH2 node (see bvh.h)
+    const float4 *tris;        // 3 x float4 per triangle slot: p0 | e1 | e2, prim id in .w of the first
+    // geometry attributes
+    const float *positions, *normals, *texcoords;
+    const uint32_t *faces, *face_shape;
+    const DShape *shapes; const DBsdf *bsdfs; const DTexture *textures; const DMedium *media; const DEmitter *emitters;
+    const float *tex_data;
+    const float4 *env_data;    // (w+1) x h RGBx
+    const float *env_hier;
+    uint32_t n_faces, n_emitters;
+    int32_t root_is_leaf, has_null_bsdf;
+    uint32_t root_leaf_first, root_leaf_count;
+    DCamera cam; DFilm film; DEnv env;
+};
+
+struct DRenderParams {
+    int32_t integrator, max_depth, rr_depth, hide_emitters;
+    uint32_t spp, log2_spp;    // log2_spp = 0xffffffff when spp is not a power of two
+    uint32_t seed_value;       // sampler base seed + render seed
+    uint32_t tile_rank, tile_count;
+    uint32_t tiles_x, tiles_y, pad;
+    uint64_t n_lanes;          // lanes this rank renders
+};
+
+// Path-state streams (SoA, one float4 / uint2 per path and stream)
+struct DPathStreams {
+    float4 *o_maxt;            // ray origin, maxt
+    float4 *d_eta;             // ray direction, eta
+    float4 *tp_pdf;            // throughput rgb, last_scatter_direction_pdf
+    float4 *res_flags;         // result rgb, packed flags (bits)
+    float4 *lp_lane;           // last scatter position, lane id (bits)
+    uint2  *rng;               // PCG32 state
+};
+#define LRT_STATE_BYTES 88     // bytes per path record across all streams
+
+// flag word layout
+#define PF_DEPTH_MASK   0x0000ffffu
+#define PF_MEDIUM_SHIFT 16             // (medium index + 1), 8 bits
+#define PF_MEDIUM_MASK  0x00ff0000u
+#define PF_CHANNEL_SHIFT 24            // 2 bits
+#define PF_SPECULAR     (1u << 26)     // volpath specular_chain / path prev_bsdf_delta
+#define PF_VALID        (1u << 27)
+
+struct DCounters {             // device-resident queue / statistics words
+    uint32_t n_in, n_out;
+    uint32_t pad[2];
+    unsigned long long n_shadow;
+    unsigned long long n_iter;
+};
+
+} // namespace lrt

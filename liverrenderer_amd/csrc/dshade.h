@@ -1,0 +1,552 @@
+// Device functions of the hip_ad_rgb hot path: BVH traversal, surface
+// interactions, BSDFs, phase functions, media and emitters.  Each function
+// cites the reference lines it implements (paths relative to the reference).
+#pragma once
+#include "device_types.h"
+#include "dmath.h"
+#include "../../include/liverrt.h"
+
+namespace lrt {
+
+#define LRT_BLOCK 256
+#define LRT_STACK 32
+
+struct Ray { V3 o, d; float maxt; };
+struct Hit { float t, u, v; uint32_t prim; };
+struct SI { bool valid; float t; V3 p, n; Frame sh; V2 uv; V3 dp_du, dp_dv, wi; uint32_t prim, shape; };
+
+// ------------------------------------------------------------- traversal
+// Moeller-Trumbore on a pre-gathered triangle slot (include/mitsuba/render/mesh.h:506-527).
+// Ties are resolved towards the lower primitive index so that the result does
+// not depend on the traversal order.
+DEV void test_tri(const float4 *__restrict__ tris, uint32_t slot, V3 o, V3 d, float maxt, Hit &best) {
+    float4 a = tris[3 * slot], b = tris[3 * slot + 1], c = tris[3 * slot + 2];
+    V3 p0(a.x, a.y, a.z), e1(b.x, b.y, b.z), e2(c.x, c.y, c.z);
+    uint32_t f = f2u(a.w);
+    V3 pvec = cross(d, e2);
+    float inv_det = rcp(dot(e1, pvec));
+    V3 tvec = o - p0;
+    float u = dot(tvec, pvec) * inv_det;
+    if (!(u >= 0.f && u <= 1.f)) return;
+    V3 qvec = cross(tvec, e1);
+    float v = dot(d, qvec) * inv_det;
+    if (!(v >= 0.f && u + v <= 1.f)) return;
+    float t = dot(e2, qvec) * inv_det;
+    if (!(t >= 0.f && t <= maxt)) return;
+    if (t < best.t || (t == best.t && f < best.prim)) { best.t = t; best.u = u; best.v = v; best.prim = f; }
+}
+
+// Stack-based BVH2 traversal; the per-lane stack lives in LDS, laid out
+// [entry][thread] so that a wave's pushes/pops hit 64 consecutive banks.
+template <bool ANY_HIT>
+DEV Hit trace(const DScene &sc, const Ray &r, int *__restrict__ stack /* &lds[threadIdx.x] */) {
+    Hit best; best.t = kInf; best.u = best.v = 0.f; best.prim = 0xffffffffu;
+    if (sc.n_faces == 0) return best;
+    const V3 o = r.o, d = r.d;
+    if (sc.root_is_leaf) {
+        for (uint32_t i = 0; i < sc.root_leaf_count; ++i) test_tri(sc.tris, sc.root_leaf_first + i, o, d, r.maxt, best);
+        return best;
+    }
+    const float ix = 1.f / d.x, iy = 1.f / d.y, iz = 1.f / d.z;
+    int sp = 0, node = 0;
+    for (;;) {
+        // ---- inner node: test both children
+        const float4 *nd = sc.nodes + 4 * (size_t) node;
+        float4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3];
+        float limit = fmin_(best.t, r.maxt);
+        float t0, t1, tmin0, tmax0, tmin1, tmax1;
+        t0 = (n0.x - o.x) * ix; t1 = (n0.y - o.x) * ix; tmin0 = fmax_(0.f, fmin_(t0, t1)); tmax0 = fmin_(limit, fmax_(t0, t1));
+        t0 = (n0.z - o.y) * iy; t1 = (n0.w - o.y) * iy; tmin0 = fmax_(tmin0, fmin_(t0, t1)); tmax0 = fmin_(tmax0, fmax_(t0, t1));
+        t0 = (n2.x - o.z) * iz; t1 = (n2.y - o.z) * iz; tmin0 = fmax_(tmin0, fmin_(t0, t1)); tmax0 = fmin_(tmax0, fmax_(t0, t1));
+        t0 = (n1.x - o.x) * ix; t1 = (n1.y - o.x) * ix; tmin1 = fmax_(0.f, fmin_(t0, t1)); tmax1 = fmin_(limit, fmax_(t0, t1));
+        t0 = (n1.z - o.y) * iy; t1 = (n1.w - o.y) * iy; tmin1 = fmax_(tmin1, fmin_(t0, t1)); tmax1 = fmin_(tmax1, fmax_(t0, t1));
+        t0 = (n2.z - o.z) * iz; t1 = (n2.w - o.z) * iz; tmin1 = fmax_(tmin1, fmin_(t0, t1)); tmax1 = fmin_(tmax1, fmax_(t0, t1));
+        bool h0 = tmin0 <= tmax0 * 1.0000005f + 1e-30f, h1 = tmin1 <= tmax1 * 1.0000005f + 1e-30f;
+        int r0 = (int) f2u(n3.x), r1 = (int) f2u(n3.y);
+        int next = 0x7fffffff;            // sentinel: nothing to descend into
+        if (h0 && h1) {
+            bool swap = tmin1 < tmin0;
+            int nearr = swap ? r1 : r0, farr = swap ? r0 : r1;
+            int nearc = swap ? (int) f2u(n3.w) : (int) f2u(n3.z), farc = swap ? (int) f2u(n3.z) : (int) f2u(n3.w);
+            // leaves are processed immediately, inner nodes are visited / pushed
+            if (farr < 0) { uint32_t first = (uint32_t) ~farr; for (int i = 0; i < farc; ++i) test_tri(sc.tris, first + i, o, d, r.maxt, best); }
+            if (nearr < 0) { uint32_t first = (uint32_t) ~nearr; for (int i = 0; i < nearc; ++i) test_tri(sc.tris, first + i, o, d, r.maxt, best); }
+            if (nearr >= 0) { next = nearr; if (farr >= 0) { stack[sp * LRT_BLOCK] = farr; ++sp; } }
+            else if (farr >= 0) next = farr;
+        } else if (h0 || h1) {
+            int rr = h0 ? r0 : r1, cc = h0 ? (int) f2u(n3.z) : (int) f2u(n3.w);
+            if (rr < 0) { uint32_t first = (uint32_t) ~rr; for (int i = 0; i < cc; ++i) test_tri(sc.tris, first + i, o, d, r.maxt, best); }
+            else next = rr;
+        }
+        if (ANY_HIT && best.prim != 0xffffffffu) return best;
+        if (next == 0x7fffffff) {
+            if (sp == 0) break;
+            --sp; next = stack[sp * LRT_BLOCK];
+        }
+        node = next;
+    }
+    return best;
+}
+
+// --------------------------------------------------- surface interaction
+// src/render/mesh.cpp:1489-1659 + include/mitsuba/render/interaction.h:290-300,516-536
+DEV SI compute_si(const DScene &sc, const Ray &r, const Hit &h) {
+    SI si;
+    si.valid = h.prim != 0xffffffffu;
+    if (!si.valid) {
+        si.t = kInf; si.wi = -r.d; si.shape = 0xffffffffu; si.prim = 0xffffffffu;
+        si.p = V3(0.f); si.n = V3(0.f); si.uv = { 0.f, 0.f }; si.dp_du = V3(0.f); si.dp_dv = V3(0.f);
+        si.sh.s = V3(0.f); si.sh.t = V3(0.f); si.sh.n = V3(0.f);
+        return si;
+    }
+    uint32_t f = h.prim, shp = sc.face_shape[f];
+    const DShape sd = sc.shapes[shp];
+    uint32_t i0 = sc.faces[3 * f], i1 = sc.faces[3 * f + 1], i2 = sc.faces[3 * f + 2];
+    V3 p0(sc.positions[3 * i0], sc.positions[3 * i0 + 1], sc.positions[3 * i0 + 2]);
+    V3 p1(sc.positions[3 * i1], sc.positions[3 * i1 + 1], sc.positions[3 * i1 + 2]);
+    V3 p2(sc.positions[3 * i2], sc.positions[3 * i2 + 1], sc.positions[3 * i2 + 2]);
+    float b1 = h.u, b2 = h.v, b0 = 1.f - b1 - b2;
+    si.t = h.t; si.prim = f; si.shape = shp;
+    si.p = V3(fma_(p0.x, b0, fma_(p1.x, b1, p2.x * b2)), fma_(p0.y, b0, fma_(p1.y, b1, p2.y * b2)), fma_(p0.z, b0, fma_(p1.z, b1, p2.z * b2)));
+    V3 dp0 = p1 - p0, dp1 = p2 - p0;
+    si.n = normalize(cross(dp0, dp1));
+    si.uv = { b1, b2 };
+    coordinate_system(si.n, &si.dp_du, &si.dp_dv);
+    if (sd.has_texcoords) {
+        V2 uv0 = { sc.texcoords[2 * i0], sc.texcoords[2 * i0 + 1] }, uv1 = { sc.texcoords[2 * i1], sc.texcoords[2 * i1 + 1] },
+           uv2 = { sc.texcoords[2 * i2], sc.texcoords[2 * i2 + 1] };
+        si.uv = { fma_(uv2.x, b2, fma_(uv1.x, b1, uv0.x * b0)), fma_(uv2.y, b2, fma_(uv1.y, b1, uv0.y * b0)) };
+        V2 duv0 = { uv1.x - uv0.x, uv1.y - uv0.y }, duv1 = { uv2.x - uv0.x, uv2.y - uv0.y };
+        float det = fma_(duv0.x, duv1.y, -(duv0.y * duv1.x)), inv_det = rcp(det);
+        if (det != 0.f) {
+            si.dp_du = V3(fma_(duv1.y, dp0.x, -(duv0.y * dp1.x)), fma_(duv1.y, dp0.y, -(duv0.y * dp1.y)), fma_(duv1.y, dp0.z, -(duv0.y * dp1.z))) * inv_det;
+            si.dp_dv = V3(fma_(-duv1.x, dp0.x, duv0.x * dp1.x), fma_(-duv1.x, dp0.y, duv0.x * dp1.y), fma_(-duv1.x, dp0.z, duv0.x * dp1.z)) * inv_det;
+        }
+    }
+    if (sd.has_normals) {
+        V3 n0(sc.normals[3 * i0], sc.normals[3 * i0 + 1], sc.normals[3 * i0 + 2]);
+        V3 n1(sc.normals[3 * i1], sc.normals[3 * i1 + 1], sc.normals[3 * i1 + 2]);
+        V3 n2(sc.normals[3 * i2], sc.normals[3 * i2 + 1], sc.normals[3 * i2 + 2]);
+        V3 n(fma_(n2.x, b2, fma_(n1.x, b1, n0.x * b0)), fma_(n2.y, b2, fma_(n1.y, b1, n0.y * b0)), fma_(n2.z, b2, fma_(n1.z, b1, n0.z * b0)));
+        float il = rsqrt_(squared_norm(n));
+        si.sh.n = n * il;
+    } else si.sh.n = si.n;
+    if (sd.flip_normals) { si.n = -si.n; si.sh.n = -si.sh.n; }
+    si.sh.s = normalize(fma3(si.sh.n, -dot(si.sh.n, si.dp_du), si.dp_du));
+    if (si.dp_du.x == 0.f && si.dp_du.y == 0.f && si.dp_du.z == 0.f) { V3 tmp; coordinate_system(si.sh.n, &si.sh.s, &tmp); }
+    si.sh.t = cross(si.sh.n, si.sh.s);
+    si.wi = si.sh.to_local(-r.d);
+    return si;
+}
+
+// include/mitsuba/render/interaction.h:140-168
+DEV V3 offset_p(V3 p, V3 n, V3 d) {
+    float mag = (1.f + max3(abs3(p))) * kRayEpsilon;
+    mag = mulsign(mag, dot(n, d));
+    return fma3(n, mag, p);
+}
+DEV Ray spawn_ray(V3 p, V3 n, V3 d) { Ray r; r.o = offset_p(p, n, d); r.d = d; r.maxt = kLargest; return r; }
+DEV Ray spawn_ray_to(V3 p, V3 n, V3 t) {
+    Ray r; r.o = offset_p(p, n, t - p);
+    V3 d = t - r.o; float dist = norm(d);
+    r.d = d / dist; r.maxt = dist * (1.f - kShadowEpsilon);
+    return r;
+}
+
+// --------------------------------------------------------------- warping
+// include/mitsuba/core/warp.h:54-92, :412-420, :250-256
+DEV V2 square_to_uniform_disk_concentric(float sx, float sy) {
+    float x = fma_(2.f, sx, -1.f), y = fma_(2.f, sy, -1.f);
+    bool is_zero = (x == 0.f) && (y == 0.f), q13 = __builtin_fabsf(x) < __builtin_fabsf(y);
+    float r = q13 ? y : x, rp = q13 ? x : y;
+    float phi = 0.25f * kPi * rp / r;
+    if (q13) phi = 0.5f * kPi - phi;
+    if (is_zero) phi = 0.f;
+    float s, c; m_sincos(phi, &s, &c);
+    return { r * c, r * s };
+}
+DEV V3 square_to_cosine_hemisphere(float sx, float sy) {
+    V2 p = square_to_uniform_disk_concentric(sx, sy);
+    float z = safe_sqrt(1.f - fma_(p.x, p.x, p.y * p.y));
+    return V3(p.x, p.y, z);
+}
+DEV V3 square_to_uniform_sphere(float sx, float sy) {
+    float z = fma_(-2.f, sy, 1.f), r = safe_sqrt(fma_(-z, z, 1.f));
+    float s, c; m_sincos(2.f * kPi * sx, &s, &c);
+    return V3(r * c, r * s, z);
+}
+
+// -------------------------------------------------------------- textures
+DEV V3 tex_eval(const DScene &sc, int tex, const SI &si) {
+    const DTexture &T = sc.textures[tex];
+    if (T.type == LRT_TEX_CHECKERBOARD) {        // src/textures/checkerboard.cpp:70-88
+        float u = fma_(T.to_uv[1], si.uv.y, fma_(T.to_uv[0], si.uv.x, T.to_uv[2]));
+        float v = fma_(T.to_uv[4], si.uv.y, fma_(T.to_uv[3], si.uv.x, T.to_uv[5]));
+        bool mx = u - __builtin_floorf(u) > .5f, my = v - __builtin_floorf(v) > .5f;
+        return (mx == my) ? V3(T.color0[0], T.color0[1], T.color0[2]) : V3(T.color1[0], T.color1[1], T.color1[2]);
+    }
+    if (T.type == LRT_TEX_RGB) return V3(T.color0[0], T.color0[1], T.color0[2]);
+    return V3(0.f);
+}
+
+// src/textures/bitmap.cpp:509-578 eval_1_grad; texels hold the per-texel
+// luminance (precomputed on the host with the same float expression).
+DEV V2 tex_eval_1_grad(const DScene &sc, int tex, const SI &si) {
+    const DTexture &T = sc.textures[tex];
+    if (T.type != LRT_TEX_BITMAP) return { 0.f, 0.f };
+    float u = fma_(T.to_uv[1], si.uv.y, fma_(T.to_uv[0], si.uv.x, T.to_uv[2]));
+    float v = fma_(T.to_uv[4], si.uv.y, fma_(T.to_uv[3], si.uv.x, T.to_uv[5]));
+    int w = T.width, h = T.height;
+    float fx = fma_(u, (float) w, -0.5f), fy = fma_(v, (float) h, -0.5f);
+    int ix = (int) __builtin_floorf(fx), iy = (int) __builtin_floorf(fy);
+    float w1x = fx - (float) ix, w1y = fy - (float) iy, w0x = 1.f - w1x, w0y = 1.f - w1y;
+    int x0 = ix % w; if (x0 < 0) x0 += w; int x1 = (ix + 1) % w; if (x1 < 0) x1 += w;
+    int y0 = iy % h; if (y0 < 0) y0 += h; int y1 = (iy + 1) % h; if (y1 < 0) y1 += h;
+    const float *d = sc.tex_data + T.data_offset;
+    float f00 = d[y0 * w + x0], f10 = d[y0 * w + x1], f01 = d[y1 * w + x0], f11 = d[y1 * w + x1];
+    float dx = fma_(w0y, f10 - f00, w1y * (f11 - f01)), dy = fma_(w0x, f01 - f00, w1x * (f11 - f10));
+    float du = T.to_uv[0] * dx + T.to_uv[3] * dy, dv = T.to_uv[1] * dx + T.to_uv[4] * dy;
+    return { (float) w * du, (float) h * dv };
+}
+
+// ----------------------------------------------------------------- BSDFs
+enum { F_DELTA = 1, F_SMOOTH = 2, F_NULL = 4 };
+struct BSDFSample { V3 wo; float pdf, eta; int type; };
+
+// include/mitsuba/render/fresnel.h:35-73
+DEV void fresnel(float cos_theta_i, float eta, float *r, float *cos_theta_t, float *eta_it, float *eta_ti) {
+    bool outside = cos_theta_i >= 0.f;
+    float rcp_eta = rcp(eta);
+    *eta_it = outside ? eta : rcp_eta; *eta_ti = outside ? rcp_eta : eta;
+    float cos_theta_t_sqr = fma_(-fma_(-cos_theta_i, cos_theta_i, 1.f), *eta_ti * *eta_ti, 1.f);
+    float cti = __builtin_fabsf(cos_theta_i), ctt = safe_sqrt(cos_theta_t_sqr);
+    bool index_matched = eta == 1.f, special = index_matched || cti == 0.f;
+    float r_sc = index_matched ? 0.f : 1.f;
+    float a_s = fma_(-*eta_it, ctt, cti) / fma_(*eta_it, ctt, cti);
+    float a_p = fma_(-*eta_it, cti, ctt) / fma_(*eta_it, cti, ctt);
+    float rr = 0.5f * (sqr(a_s) + sqr(a_p));
+    if (special) rr = r_sc;
+    *r = rr; *cos_theta_t = mulsign_neg(ctt, cos_theta_i);
+}
+
+// src/bsdfs/bumpmap.cpp:226-251
+DEV Frame bump_frame(const DScene &sc, const DBsdf &B, const SI &si) {
+    V2 g = tex_eval_1_grad(sc, B.texture, si);
+    float gx = B.scale * g.x, gy = B.scale * g.y;
+    V3 dp_du = fma3(si.sh.n, gx - dot(si.sh.n, si.dp_du), si.dp_du);
+    V3 dp_dv = fma3(si.sh.n, gy - dot(si.sh.n, si.dp_dv), si.dp_dv);
+    Frame r;
+    r.n = normalize(cross(dp_du, dp_dv));
+    if (dot(si.n, r.n) < 0.f) r.n = r.n * -1.f;
+    r.n = si.sh.to_local(r.n);
+    if (si.wi.z * dot(si.wi, r.n) <= 0.f) r.n = V3(-r.n.x, -r.n.y, r.n.z);
+    r.s = normalize(fma3(r.n, -dot(r.n, si.dp_du), si.dp_du));
+    r.t = cross(r.n, r.s);
+    return r;
+}
+DEV float tan_theta_2(V3 v) { float t = fma_(-v.z, v.z, 1.f); return fmax_(t, 0.f) / sqr(v.z); }
+DEV float shadow_terminator(V3 pn, V3 wo) {       // src/bsdfs/normalmap_helpers.h:20-25
+    float alpha2 = fmin_(0.125f * tan_theta_2(pn), 1.f);
+    return 2.f / (1.f + __builtin_sqrtf(1.f + alpha2 * tan_theta_2(wo)));
+}
+
+// Leaf BSDFs (diffuse / dielectric / null), evaluated in the frame `wi` is given in.
+DEV void leaf_sample(const DScene &sc, const DBsdf &B, const SI &si, V3 wi, float s1, float s2x, float s2y, BSDFSample *bs, V3 *weight) {
+    bs->wo = V3(0.f); bs->pdf = 0.f; bs->eta = 0.f; bs->type = 0; *weight = V3(0.f);
+    if (B.type == LRT_BSDF_DIFFUSE) {               // src/bsdfs/diffuse.cpp sample()
+        if (!(wi.z > 0.f)) return;
+        bs->wo = square_to_cosine_hemisphere(s2x, s2y);
+        bs->pdf = kInvPi * bs->wo.z; bs->eta = 1.f; bs->type = F_SMOOTH;
+        if (bs->pdf > 0.f) *weight = tex_eval(sc, B.reflectance, si);
+    } else if (B.type == LRT_BSDF_DIELECTRIC) {     // src/bsdfs/dielectric.cpp:230-367
+        float r_i, ctt, eta_it, eta_ti;
+        fresnel(wi.z, B.eta, &r_i, &ctt, &eta_it, &eta_ti);
+        float t_i = 1.f - r_i;
+        bool sel_r = s1 <= r_i;
+        bs->pdf = sel_r ? r_i : t_i;
+        bs->type = F_DELTA;
+        bs->wo = sel_r ? V3(-wi.x, -wi.y, wi.z) : V3(-eta_ti * wi.x, -eta_ti * wi.y, ctt);
+        bs->eta = sel_r ? 1.f : eta_it;
+        *weight = V3(1.f);
+        if (!sel_r) *weight = *weight * sqr(eta_ti);
+    } else {                                       // src/bsdfs/null.cpp sample()
+        bs->wo = -wi; bs->type = F_NULL; bs->eta = 1.f; bs->pdf = 1.f; *weight = V3(1.f);
+    }
+}
+DEV V3 leaf_eval(const DScene &sc, const DBsdf &B, const SI &si, V3 wi, V3 wo) {
+    if (B.type == LRT_BSDF_DIFFUSE) {
+        if (!(wi.z > 0.f && wo.z > 0.f)) return V3(0.f);
+        return tex_eval(sc, B.reflectance, si) * kInvPi * wo.z;
+    }
+    return V3(0.f);
+}
+DEV float leaf_pdf(const DBsdf &B, V3 wi, V3 wo) {
+    if (B.type == LRT_BSDF_DIFFUSE) return (wi.z > 0.f && wo.z > 0.f) ? kInvPi * wo.z : 0.f;
+    return 0.f;
+}
+
+DEV void bsdf_sample(const DScene &sc, int b, const SI &si, float s1, float s2x, float s2y, BSDFSample *bs, V3 *weight) {
+    const DBsdf B = sc.bsdfs[b];
+    if (B.type == LRT_BSDF_BUMPMAP) {               // src/bsdfs/bumpmap.cpp:138-162
+        Frame pf = bump_frame(sc, B, si);
+        V3 pwi = pf.to_local(si.wi);
+        V3 w; leaf_sample(sc, sc.bsdfs[B.nested], si, pwi, s1, s2x, s2y, bs, &w);
+        bool active = any_nonzero(w);
+        V3 pwo = pf.to_world(bs->wo);
+        active = active && (bs->wo.z * pwo.z > 0.f);
+        bs->wo = pwo;
+        w = w * shadow_terminator(pf.n, bs->wo);
+        *weight = active ? w : V3(0.f);
+    } else leaf_sample(sc, B, si, si.wi, s1, s2x, s2y, bs, weight);
+}
+DEV V3 bsdf_eval(const DScene &sc, int b, const SI &si, V3 wo) {
+    const DBsdf B = sc.bsdfs[b];
+    if (B.type == LRT_BSDF_BUMPMAP) {               // src/bsdfs/bumpmap.cpp:164-183
+        Frame pf = bump_frame(sc, B, si);
+        V3 pwi = pf.to_local(si.wi), pwo = pf.to_local(wo);
+        if (!(wo.z * pwo.z > 0.f)) return V3(0.f);
+        return leaf_eval(sc, sc.bsdfs[B.nested], si, pwi, pwo) * shadow_terminator(pf.n, wo);
+    }
+    return leaf_eval(sc, B, si, si.wi, wo);
+}
+DEV float bsdf_pdf(const DScene &sc, int b, const SI &si, V3 wo) {
+    const DBsdf B = sc.bsdfs[b];
+    if (B.type == LRT_BSDF_BUMPMAP) {
+        Frame pf = bump_frame(sc, B, si);
+        V3 pwi = pf.to_local(si.wi), pwo = pf.to_local(wo);
+        if (!(wo.z * pwo.z > 0.f)) return 0.f;
+        return leaf_pdf(sc.bsdfs[B.nested], pwi, pwo);
+    }
+    return leaf_pdf(B, si.wi, wo);
+}
+DEV float bsdf_null_transmission(const DScene &sc, int b) { return sc.bsdfs[b].type == LRT_BSDF_NULL ? 1.f : 0.f; }
+
+// -------------------------------------------------------------- emitters
+struct DirSample { V3 p, n, d; float pdf, dist; bool delta; int emitter; };
+
+// include/mitsuba/core/distr_2d.h:517-602 + include/mitsuba/core/warp.h:446-494
+DEV float interval_to_linear(float v0, float v1, float sample) {
+    if (__builtin_fabsf(v0 - v1) > 1e-4f * (v0 + v1))
+        return (v0 - safe_sqrt(lerpf(sqr(v0), sqr(v1), sample))) / (v0 - v1);
+    return sample;
+}
+DEV void hier_sample(const DScene &sc, float sx, float sy, float *ox, float *oy, float *pdf) {
+    const DEnv &E = sc.env;
+    sx = clampf(sx, 0.f, 1.f); sy = clampf(sy, 0.f, 1.f);
+    uint32_t offx = 0, offy = 0;
+    for (int l = E.n_levels - 2; l > 0; --l) {
+        offx <<= 1; offy <<= 1;
+        uint32_t width = E.level_width[l];
+        uint32_t oi = ((offx & 1u) | (((offx & ~1u) | (offy & 1u)) << 1)) + ((offy & ~1u) * width);
+        const float4 q = *reinterpret_cast<const float4 *>(sc.env_hier + E.level_offset[l] + oi);   // 2x2 patches are contiguous
+        float v00 = q.x, v10 = q.y, v01 = q.z, v11 = q.w;
+        sx = clampf(sx, 0.f, 1.f); sy = clampf(sy, 0.f, 1.f);
+        float r0 = v00 + v10, r1 = v01 + v11;
+        sy *= r0 + r1;
+        bool mask = sy > r0;
+        if (mask) { offy += 1; sy -= r0; }
+        sy /= mask ? r1 : r0;
+        float c0 = mask ? v01 : v00, c1 = mask ? v11 : v10;
+        sx *= c0 + c1;
+        mask = sx > c0;
+        if (mask) sx -= c0;
+        sx /= mask ? c1 : c0;
+        if (mask) offx += 1;
+    }
+    uint32_t w0 = E.level_width[0];
+    const float *l0 = sc.env_hier + E.level_offset[0];
+    uint32_t oi = offx + offy * w0;
+    float v00 = l0[oi], v10 = l0[oi + 1], v01 = l0[oi + w0], v11 = l0[oi + w0 + 1];
+    float r0 = v00 + v10, r1 = v01 + v11;
+    sy = interval_to_linear(r0, r1, sy);
+    float c0 = lerpf(v00, v01, sy), c1 = lerpf(v10, v11, sy);
+    sx = interval_to_linear(c0, c1, sx);
+    *pdf = lerpf(c0, c1, sx);
+    *ox = ((float) (int) offx + sx) * E.patch_size[0];
+    *oy = ((float) (int) offy + sy) * E.patch_size[1];
+}
+// include/mitsuba/core/distr_2d.h:695-726
+DEV float hier_eval(const DScene &sc, float px, float py) {
+    const DEnv &E = sc.env;
+    px = clampf(px, 0.f, 1.f); py = clampf(py, 0.f, 1.f);
+    px *= E.inv_patch_size[0]; py *= E.inv_patch_size[1];
+    uint32_t ox = min((uint32_t) (int) px, E.max_patch[0]), oy = min((uint32_t) (int) py, E.max_patch[1]);
+    px -= (float) (int) ox; py -= (float) (int) oy;
+    uint32_t w0 = E.level_width[0];
+    const float *l0 = sc.env_hier + E.level_offset[0];
+    uint32_t oi = ox + oy * w0;
+    float v00 = l0[oi], v10 = l0[oi + 1], v01 = l0[oi + w0], v11 = l0[oi + w0 + 1];
+    return lerpf(lerpf(v00, v10, px), lerpf(v01, v11, px), py);
+}
+
+// src/emitters/envmap.cpp:528-560
+DEV V3 env_eval_uv(const DScene &sc, float u, float v) {
+    const DEnv &E = sc.env;
+    uint32_t rx = E.w, ry = E.h;
+    u -= .5f / (float) (rx - 1u);
+    u -= __builtin_floorf(u); v -= __builtin_floorf(v);
+    u *= (float) (rx - 1u); v *= (float) (ry - 1u);
+    uint32_t px = min((uint32_t) u, rx - 2u), py = min((uint32_t) v, ry - 2u);
+    float w1x = u - (float) px, w1y = v - (float) py, w0x = 1.f - w1x, w0y = 1.f - w1y;
+    uint32_t idx = py * rx + px;
+    float4 a = sc.env_data[idx], b = sc.env_data[idx + 1], c = sc.env_data[idx + rx], d = sc.env_data[idx + rx + 1];
+    V3 v00(a.x, a.y, a.z), v10(b.x, b.y, b.z), v01(c.x, c.y, c.z), v11(d.x, d.y, d.z);
+    V3 t0 = v10 * w1x, t1 = v11 * w1x;
+    V3 v0(fma_(w0x, v00.x, t0.x), fma_(w0x, v00.y, t0.y), fma_(w0x, v00.z, t0.z));
+    V3 v1(fma_(w0x, v01.x, t1.x), fma_(w0x, v01.y, t1.y), fma_(w0x, v01.z, t1.z));
+    V3 t2 = v1 * w1y;
+    V3 vv(fma_(w0y, v0.x, t2.x), fma_(w0y, v0.y, t2.y), fma_(w0y, v0.z, t2.z));
+    return vv * E.scale;
+}
+DEV V3 emitter_eval_env(const DScene &sc, V3 dir_world) {
+    const DEnv &E = sc.env;
+    if (E.type == LRT_EMITTER_CONSTANT) return V3(E.radiance[0], E.radiance[1], E.radiance[2]);
+    V3 v = xform_vec9(E.to_local, dir_world);           // src/emitters/envmap.cpp:353-362
+    float uu = m_atan2(v.x, -v.z) * kInvTwoPi, vv = safe_acos(v.y) * kInvPi;
+    return env_eval_uv(sc, uu, vv);
+}
+
+// Scene::sample_emitter_direction without visibility test (src/render/scene.cpp:333-383)
+DEV V3 sample_emitter_direction(const DScene &sc, V3 ref_p, float sx, float sy, DirSample *ds) {
+    uint32_t ne = sc.n_emitters;
+    ds->p = V3(0.f); ds->n = V3(0.f); ds->d = V3(0.f); ds->pdf = 0.f; ds->dist = 0.f; ds->delta = false; ds->emitter = -1;
+    if (ne == 0) return V3(0.f);
+    uint32_t index = 0; float emitter_weight = 1.f, pmf = 1.f;
+    if (ne > 1) {
+        float scaled = sx * (float) ne;
+        index = min((uint32_t) scaled, ne - 1u);
+        emitter_weight = (float) ne; sx = scaled - (float) index; pmf = 1.f / (float) ne;
+    }
+    const DEmitter &E = sc.emitters[index];
+    ds->emitter = (int) index;
+    V3 spec(0.f);
+    if (E.type == LRT_EMITTER_AREA) {
+        // src/shapes/rectangle.cpp:181-199, src/render/shape.cpp:343-361, src/emitters/area.cpp sample_direction
+        ds->p = xform_point12(E.to_world, V3(fma_(sx, 2.f, -1.f), fma_(sy, 2.f, -1.f), 0.f));
+        ds->n = V3(E.n[0], E.n[1], E.n[2]);
+        ds->pdf = E.inv_area;
+        ds->d = ds->p - ref_p;
+        float dist2 = squared_norm(ds->d);
+        ds->dist = __builtin_sqrtf(dist2);
+        ds->d = ds->d / ds->dist;
+        float dp = __builtin_fabsf(dot(ds->d, ds->n)), x = dist2 / dp;
+        ds->pdf *= finite_(x) ? x : 0.f;
+        bool active = dot(ds->d, ds->n) < 0.f && ds->pdf != 0.f;
+        V3 rad(E.radiance[0], E.radiance[1], E.radiance[2]);
+        spec = active ? rad / ds->pdf : V3(0.f);
+    } else if (E.type == LRT_EMITTER_ENVMAP) {          // src/emitters/envmap.cpp:415-459
+        const DEnv &EV = sc.env;
+        float u, v, pdf; hier_sample(sc, sx, sy, &u, &v, &pdf);
+        u += .5f / (float) (EV.w - 1u);
+        bool active = pdf > 0.f;
+        float theta = v * kPi, phi = u * kTwoPi;
+        float st, ct, sp, cp; m_sincos(theta, &st, &ct); m_sincos(phi, &sp, &cp);
+        V3 d(cp * st, sp * st, ct);
+        d = V3(d.y, d.z, -d.x);
+        V3 c(EV.bsphere_c[0], EV.bsphere_c[1], EV.bsphere_c[2]);
+        float radius = fmax_(EV.bsphere_r, norm(ref_p - c)), dist = 2.f * radius;
+        float inv_sin_theta = safe_rsqrt(fmax_(sqr(d.x) + sqr(d.z), sqr(kEpsilon)));
+        d = xform_vec9(EV.to_world, d);
+        ds->p = ref_p + d * dist; ds->n = -d;
+        ds->pdf = active ? pdf * inv_sin_theta * (1.f / (2.f * sqr(kPi))) : 0.f;
+        ds->d = d; ds->dist = dist;
+        V3 val = env_eval_uv(sc, u, v);
+        spec = active ? val / ds->pdf : V3(0.f);
+    } else {                                            // src/emitters/constant.cpp sample_direction
+        const DEnv &EV = sc.env;
+        V3 d = square_to_uniform_sphere(sx, sy);
+        V3 c(EV.bsphere_c[0], EV.bsphere_c[1], EV.bsphere_c[2]);
+        float radius = fmax_(EV.bsphere_r, norm(ref_p - c)), dist = 2.f * radius;
+        ds->p = fma3(d, dist, ref_p); ds->n = -d; ds->pdf = kInvFourPi; ds->d = d; ds->dist = dist;
+        spec = V3(E.radiance[0], E.radiance[1], E.radiance[2]) / ds->pdf;
+    }
+    ds->pdf *= pmf;
+    spec = spec * emitter_weight;
+    return spec;
+}
+
+// DirectionSample(scene, si, ref) + Scene::pdf_emitter_direction
+// (include/mitsuba/render/records.h:173-180, src/render/scene.cpp:395-406)
+DEV float pdf_emitter_direction(const DScene &sc, V3 ref_p, const SI &si, int emitter) {
+    V3 rel = si.p - ref_p;
+    float dist = norm(rel);
+    V3 d = si.valid ? rel / dist : -si.wi;
+    float pmf = 1.f / (float) sc.n_emitters;
+    const DEmitter &E = sc.emitters[emitter];
+    float value;
+    if (E.type == LRT_EMITTER_AREA) {
+        float dp = dot(d, si.n);
+        if (!(dp < 0.f)) return 0.f;
+        float adp = __builtin_fabsf(dp);
+        value = E.inv_area * (adp != 0.f ? (dist * dist) / adp : 0.f);
+    } else if (E.type == LRT_EMITTER_ENVMAP) {          // src/emitters/envmap.cpp:461-475
+        const DEnv &EV = sc.env;
+        V3 dl = xform_vec9(EV.to_local, d);
+        float u = m_atan2(dl.x, -dl.z) * kInvTwoPi, v = safe_acos(dl.y) * kInvPi;
+        u -= .5f / (float) (EV.w - 1u);
+        u -= __builtin_floorf(u); v -= __builtin_floorf(v);
+        float inv_sin_theta = safe_rsqrt(fmax_(sqr(dl.x) + sqr(dl.z), sqr(kEpsilon)));
+        value = hier_eval(sc, u, v) * inv_sin_theta * (1.f / (2.f * sqr(kPi)));
+    } else value = kInvFourPi;
+    return value * pmf;
+}
+
+DEV int si_emitter(const DScene &sc, const SI &si) { return si.valid ? sc.shapes[si.shape].emitter : sc.env.emitter; }
+DEV V3 emitter_eval(const DScene &sc, int e, const SI &si) {
+    if (!si.valid) return emitter_eval_env(sc, -si.wi);
+    const DEmitter &E = sc.emitters[e];                 // src/emitters/area.cpp eval()
+    return (si.wi.z > 0.f) ? V3(E.radiance[0], E.radiance[1], E.radiance[2]) : V3(0.f);
+}
+
+DEV float mis_weight(float a, float b) { a *= a; b *= b; float w = a / (a + b); return finite_(w) ? w : 0.f; }
+
+// ----------------------------------------------------------------- media
+struct MI { float t; V3 p, wi; V3 sigma_s, sigma_n, sigma_t, combined; float mint;
+            DEV bool valid() const { return t != kInf; } };
+
+// src/render/medium.cpp:40-82 + src/media/homogeneous.cpp:153-181
+DEV MI medium_sample_interaction(const DMedium &M, const Ray &ray, float sample, uint32_t channel) {
+    MI mei; mei.wi = -ray.d;
+    float mint = 0.f, maxt = fmin_(ray.maxt, kInf);
+    V3 sigmat(M.sigma_t[0], M.sigma_t[1], M.sigma_t[2]);
+    float mm = idx3(sigmat, channel);
+    float sampled_t = mint + (-m_log(1.f - sample) / mm);
+    bool valid = sampled_t <= maxt;
+    mei.t = valid ? sampled_t : kInf;
+    mei.p = fma3(ray.d, sampled_t, ray.o);
+    mei.mint = mint;
+    V3 albedo(M.albedo[0], M.albedo[1], M.albedo[2]);
+    mei.sigma_t = valid ? sigmat : V3(0.f);
+    mei.sigma_s = valid ? sigmat * albedo : V3(0.f);
+    mei.sigma_n = V3(0.f);
+    mei.combined = sigmat;
+    return mei;
+}
+
+// src/phase/hg.cpp:64-99, src/phase/isotropic.cpp:39-58
+DEV float hg_eval(float g, float cos_theta) {
+    float temp = 1.f + sqr(g) + 2.f * g * cos_theta;
+    return kInvFourPi * (1.f - sqr(g)) / (temp * __builtin_sqrtf(temp));
+}
+DEV void phase_sample(const DMedium &M, V3 wi, float s2x, float s2y, V3 *wo, float *pdf) {
+    if (M.phase == LRT_PHASE_HG) {
+        float g = M.g;
+        float sqr_term = (1.f - sqr(g)) / (1.f - g + 2.f * g * s2x);
+        float cos_theta = (1.f + sqr(g) - sqr(sqr_term)) / (2.f * g);
+        if (__builtin_fabsf(g) < kEpsilon) cos_theta = 1.f - 2.f * s2x;
+        float sin_theta = safe_sqrt(1.f - sqr(cos_theta));
+        float sp, cp; m_sincos(2.f * kPi * s2y, &sp, &cp);
+        Frame f(wi);
+        *wo = f.to_world(V3(sin_theta * cp, sin_theta * sp, -cos_theta));
+        *pdf = hg_eval(g, -cos_theta);
+    } else {
+        *wo = square_to_uniform_sphere(s2x, s2y);
+        *pdf = kInvFourPi;
+    }
+}
+DEV float phase_eval(const DMedium &M, V3 wi, V3 wo) { return M.phase == LRT_PHASE_HG ? hg_eval(M.g, dot(wo, wi)) : kInvFourPi; }
+
+DEV int target_medium(const DShape &sd, V3 d, V3 n) { return dot(d, n) > 0.f ? sd.exterior_medium : sd.interior_medium; }
+DEV bool is_medium_transition(const DShape &sd) { return sd.interior_medium >= 0 || sd.exterior_medium >= 0; }
+
+} // namespace lrt

@@ -1,0 +1,39 @@
+// Host-side scene object behind the C ABI (include/liverrt.h).
+#pragma once
+#include "../../include/liverrt.h"
+#include <string>
+#include <vector>
+#include <memory>
+
+namespace lrt {
+
+struct DeviceScene;   // device-resident data + wavefront workspace (device.hip)
+
+// Owns every array the POD description points into.
+struct SceneStorage {
+    std::vector<float> positions, normals, texcoords;
+    std::vector<uint32_t> faces, face_shape;
+    std::vector<lrt_shape_desc> shapes;
+    std::vector<lrt_bsdf_desc> bsdfs;
+    std::vector<lrt_texture_desc> textures;
+    std::vector<std::vector<float>> texdata;
+    std::vector<lrt_medium_desc> media;
+    std::vector<lrt_emitter_desc> emitters;
+    std::vector<std::vector<float>> emdata;
+    lrt_scene_desc desc{};
+    void fix_pointers();                 // re-point desc at the vectors above
+    void copy_from(const lrt_scene_desc &d);
+};
+
+// XML -> storage (loader.cpp).  Throws std::runtime_error.
+void load_scene_xml(const std::string &xml_text, const std::string &base_dir,
+                    const std::vector<std::pair<std::string, std::string>> &defines, SceneStorage &out);
+
+} // namespace lrt
+
+struct lrt_scene {
+    lrt::SceneStorage st;
+    lrt::DeviceScene *dev = nullptr;     // created lazily on first device call
+    bool params_dirty = true;
+    lrt_render_stats stats{};
+};

@@ -1,0 +1,516 @@
+// gfx950 wavefront kernels of the hip_ad_rgb hot path (included by device.hip).
+//
+//   k_raygen   SamplingIntegrator::render lane set-up + render_sample prologue
+//              (src/render/integrator.cpp:308-338,449-486; src/render/sampler.cpp:129-148;
+//               src/sensors/perspective.cpp:239-279) -> path-state streams
+//   k_iterate  one trip of the integrator's dr::while_loop for every live path
+//              (src/integrators/volpath.cpp:170-391 incl. sample_emitter :400-554,
+//               src/integrators/path.cpp:194-338), reading the in-queue streams,
+//              compacting survivors into the out-queue with __ballot/popcount and
+//              one queue atomic per workgroup, and splatting finished paths into
+//              the film (src/render/imageblock.cpp:174-232,431-500)
+//   k_develop  HDRFilm::develop (src/films/hdrfilm.cpp:306-410)
+//   k_trace    SoA ray queries (test hook, src/render/scene_native.inl:135-202)
+#pragma once
+#include "dshade.h"
+
+namespace lrt {
+
+struct PathState {
+    V3 o, d, tp, res, lp; float maxt, eta, last_pdf; uint32_t flags, lane; uint64_t rng_state;
+};
+
+DEV void load_state(const DPathStreams &q, uint32_t i, PathState &s) {
+    float4 a = q.o_maxt[i], b = q.d_eta[i], c = q.tp_pdf[i], d = q.res_flags[i], e = q.lp_lane[i]; uint2 r = q.rng[i];
+    s.o = V3(a.x, a.y, a.z); s.maxt = a.w; s.d = V3(b.x, b.y, b.z); s.eta = b.w;
+    s.tp = V3(c.x, c.y, c.z); s.last_pdf = c.w; s.res = V3(d.x, d.y, d.z); s.flags = f2u(d.w);
+    s.lp = V3(e.x, e.y, e.z); s.lane = f2u(e.w); s.rng_state = ((uint64_t) r.y << 32) | r.x;
+}
+DEV void store_state(const DPathStreams &q, uint32_t i, const PathState &s) {
+    q.o_maxt[i] = make_float4(s.o.x, s.o.y, s.o.z, s.maxt);
+    q.d_eta[i] = make_float4(s.d.x, s.d.y, s.d.z, s.eta);
+    q.tp_pdf[i] = make_float4(s.tp.x, s.tp.y, s.tp.z, s.last_pdf);
+    q.res_flags[i] = make_float4(s.res.x, s.res.y, s.res.z, u2f(s.flags));
+    q.lp_lane[i] = make_float4(s.lp.x, s.lp.y, s.lp.z, u2f(s.lane));
+    q.rng[i] = make_uint2((uint32_t) s.rng_state, (uint32_t) (s.rng_state >> 32));
+}
+
+DEV PCG32 lane_rng_fresh(uint32_t seed_value, uint32_t lane) {
+    uint32_t v0, v1; tea32(seed_value, lane, &v0, &v1);
+    PCG32 r; r.seed(v0, v1); return r;
+}
+DEV uint64_t lane_rng_inc(uint32_t seed_value, uint32_t lane) {
+    uint32_t v0, v1; tea32(seed_value, lane, &v0, &v1);
+    return ((uint64_t) v1 << 1) | 1u;
+}
+
+// lane -> pixel (src/render/integrator.cpp:321-338); tile-sharded renders go
+// through the rank's pixel list so that seeding uses the GLOBAL lane index.
+DEV void lane_to_pixel(const DScene &sc, const DRenderParams &rp, uint32_t lane, int *px, int *py) {
+    uint32_t idx = (rp.log2_spp != 0xffffffffu) ? (lane >> rp.log2_spp) : (lane / rp.spp);
+    uint32_t W = (uint32_t) sc.film.width;
+    uint32_t y = idx / W, x = idx - y * W;
+    *px = (int) x + sc.film.crop_offset_x; *py = (int) y + sc.film.crop_offset_y;
+}
+
+// src/sensors/perspective.cpp:239-279
+DEV Ray camera_ray(const DScene &sc, float ax, float ay) {
+    const float *m = sc.cam.s2c;
+    V3 p(ax + 0.f, ay + 0.f, 0.f);
+    float r[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = fma_(m[4 * i + 2], p.z, fma_(m[4 * i + 1], p.y, fma_(m[4 * i + 0], p.x, m[4 * i + 3])));
+    V3 near_p(r[0] / r[3], r[1] / r[3], r[2] / r[3]);
+    V3 d = normalize(near_p);
+    Ray ray;
+    ray.o = V3(sc.cam.to_world[3], sc.cam.to_world[7], sc.cam.to_world[11]);
+    ray.d = xform_vec12(sc.cam.to_world, d);
+    float inv_z = rcp(d.z), near_t = sc.cam.near_clip * inv_z, far_t = sc.cam.far_clip * inv_z;
+    ray.o = ray.o + ray.d * near_t;
+    ray.maxt = far_t - near_t;
+    return ray;
+}
+
+__global__ void __launch_bounds__(LRT_BLOCK)
+k_raygen(DScene sc, DRenderParams rp, DPathStreams q, const uint32_t *__restrict__ pixel_list,
+         uint64_t lane_base, uint32_t n, uint32_t slot_base) {
+    uint32_t i = blockIdx.x * LRT_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    uint64_t j = lane_base + i;                       // rank-local lane
+    uint32_t lane;
+    if (pixel_list) { uint32_t pj = (uint32_t) (j / rp.spp); lane = pixel_list[pj] * rp.spp + (uint32_t) (j - (uint64_t) pj * rp.spp); }
+    else lane = (uint32_t) j;
+    PCG32 rng = lane_rng_fresh(rp.seed_value, lane);
+    int px, py; lane_to_pixel(sc, rp, lane, &px, &py);
+    float jx = rng.next(), jy = rng.next();
+    float spx = (float) px + jx, spy = (float) py + jy;
+    Ray ray = camera_ray(sc, fma_(spx, sc.film.scale_x, sc.film.offset_x), fma_(spy, sc.film.scale_y, sc.film.offset_y));
+    PathState s;
+    s.o = ray.o; s.d = ray.d; s.maxt = ray.maxt; s.eta = 1.f; s.tp = V3(1.f); s.res = V3(0.f); s.lp = V3(0.f); s.last_pdf = 1.f; s.lane = lane;
+    bool env_visible = !rp.hide_emitters && sc.env.type >= 0;
+    uint32_t flags = env_visible ? PF_VALID : 0u;
+    if (rp.integrator == LRT_INTEGRATOR_PATH) flags |= PF_SPECULAR;                 // prev_bsdf_delta = true
+    else {
+        if (!rp.hide_emitters) flags |= PF_SPECULAR;                                 // specular_chain = active && !hide_emitters
+        uint32_t channel = min((uint32_t) (rng.next() * 3.f), 2u);                   // volpath.cpp:117-121
+        flags |= channel << PF_CHANNEL_SHIFT;
+        flags |= (uint32_t) (sc.cam.medium + 1) << PF_MEDIUM_SHIFT;
+    }
+    s.flags = flags; s.rng_state = rng.state;
+    store_state(q, slot_base + i, s);
+}
+
+// ------------------------------------------------------------------ film
+DEV float estrin10(float x, const float *c) {
+    float x2 = x * x, x4 = x2 * x2, x8 = x4 * x4;
+    float a0 = fma_(x, c[1], c[0]), a1 = fma_(x, c[3], c[2]), a2 = fma_(x, c[5], c[4]), a3 = fma_(x, c[7], c[6]), a4 = fma_(x, c[9], c[8]);
+    float b0 = fma_(x2, a1, a0), b1 = fma_(x2, a3, a2);
+    float c0 = fma_(x4, b1, b0);
+    return fma_(x8, a4, c0);
+}
+DEV float rfilter_eval(const DFilm &F, float x) {
+    if (F.rfilter == LRT_RFILTER_GAUSSIAN) return fmax_(estrin10(sqr(x), F.rf_coeff), 0.f);
+    if (F.rfilter == LRT_RFILTER_TENT) return fmax_(0.f, 1.f - __builtin_fabsf(x * F.rf_inv_radius));
+    return (__builtin_fabsf(x) <= 0.5f) ? 1.f : 0.f;
+}
+
+// A finished path: splat {R,G,B,[A],W=1} (integrator.cpp:499-520, imageblock.cpp:174-232,431-500),
+// or, for the per-lane test hook, store the radiance.
+DEV void finish_path(const DScene &sc, const DRenderParams &rp, float *__restrict__ film, float *__restrict__ sample_out,
+                     uint64_t sample_base, uint32_t lane, V3 L, bool valid) {
+    if (rp.integrator == LRT_INTEGRATOR_PATH && !valid) L = V3(0.f);                 // path.cpp:342-345
+    if (sample_out) {
+        float4 *o = reinterpret_cast<float4 *>(sample_out) + ((uint64_t) lane - sample_base);
+        *o = make_float4(L.x, L.y, L.z, valid ? 1.f : 0.f);
+        return;
+    }
+    const DFilm &F = sc.film;
+    int px, py; lane_to_pixel(sc, rp, lane, &px, &py);
+    const int C = F.channels;
+    float vals[5]; int k = 0;
+    vals[k++] = L.x; vals[k++] = L.y; vals[k++] = L.z; if (F.has_alpha) vals[k++] = valid ? 1.f : 0.f; vals[k++] = 1.f;
+    if (F.rfilter == LRT_RFILTER_BOX) {
+        int x = px - F.crop_offset_x, y = py - F.crop_offset_y;
+        float *p = film + ((size_t) y * F.width + x) * C;
+        for (int c = 0; c < C; ++c) atomicAdd(p + c, vals[c]);
+        return;
+    }
+    PCG32 rng = lane_rng_fresh(rp.seed_value, lane);                                 // the pixel jitter is the stream's first two draws
+    float jx = rng.next(), jy = rng.next();
+    float spx = (float) px + jx, spy = (float) py + jy;
+    int n = F.fn, count = F.fcount;
+    int pix = (int) __builtin_floorf(spx) - n, piy = (int) __builtin_floorf(spy) - n;
+    float relx = (float) pix + .5f - spx, rely = (float) piy + .5f - spy;
+    for (int ys = 0; ys < count; ++ys) {
+        int y = piy - F.crop_offset_y + ys;
+        float wy = rfilter_eval(F, rely + (float) ys);
+        if (y < 0 || y >= F.height || wy == 0.f) continue;
+        for (int xs = 0; xs < count; ++xs) {
+            int x = pix - F.crop_offset_x + xs;
+            if (x < 0 || x >= F.width) continue;
+            float w = wy * rfilter_eval(F, relx + (float) xs);
+            if (w == 0.f) continue;
+            float *p = film + ((size_t) y * F.width + x) * C;
+            for (int c = 0; c < C; ++c) atomicAdd(p + c, vals[c] * w);
+        }
+    }
+}
+
+// ---------------------------------------------------------- volpath NEE
+// src/integrators/volpath.cpp:400-554.  ref_n is zero for medium interactions.
+DEV V3 volpath_sample_emitter(const DScene &sc, PCG32 &rng, V3 ref_p, V3 ref_n, bool ref_is_surface, uint32_t ref_shape, V3 ref_geo_n,
+                              int medium, uint32_t channel, DirSample *ds_out, int *stack, uint32_t &n_shadow) {
+    V3 transmittance(1.f);
+    float sx = rng.next(), sy = rng.next();
+    DirSample ds; V3 emitter_val = sample_emitter_direction(sc, ref_p, sx, sy, &ds);
+    *ds_out = ds;
+    if (ds.pdf == 0.f) return V3(0.f);
+    Ray ray = spawn_ray_to(ref_p, ref_n, ds.p);
+    float max_dist = ray.maxt;
+    if (ref_is_surface) { const DShape sd = sc.shapes[ref_shape]; if (is_medium_transition(sd)) medium = target_medium(sd, ray.d, ref_geo_n); }
+    float total_dist = 0.f;
+    SI si; si.valid = false; si.t = 0.f; si.shape = 0; si.p = V3(0.f); si.n = V3(0.f);
+    bool needs_intersection = true, active = true;
+    while (active) {
+        float remaining_dist = max_dist - total_dist;
+        ray.maxt = remaining_dist;
+        if (!(remaining_dist > 0.f)) break;
+        bool escaped_medium = false, active_medium = medium >= 0, active_surface = !active_medium;
+        if (active_medium) {
+            const DMedium M = sc.media[medium];
+            MI mei = medium_sample_interaction(M, ray, rng.next(), channel);
+            if (mei.valid()) ray.maxt = fmin_(mei.t, remaining_dist);
+            if (needs_intersection) {
+                // Exact shortcut: a real collision (sigma_n = 0) kills the sample whether or not a
+                // surface lies in front of it when every surface blocks (no null BSDF): skip the query.
+                bool elide = mei.valid() && !sc.has_null_bsdf;
+                if (!elide) { n_shadow++; Hit h = trace<false>(sc, ray, stack); si = compute_si(sc, ray, h); }
+                else { si.valid = false; si.t = kInf; }
+            }
+            if (si.t < mei.t) mei.t = kInf;
+            needs_intersection = false;
+            bool spectral = M.has_spectral_extinction;
+            if (spectral) {
+                float t = fmin_(remaining_dist, fmin_(mei.t, si.t)) - mei.mint;
+                V3 tr(m_exp(-t * mei.combined.x), m_exp(-t * mei.combined.y), m_exp(-t * mei.combined.z));
+                V3 ffp = (si.t < mei.t || mei.t > remaining_dist) ? tr : tr * mei.combined;
+                float tr_pdf = idx3(ffp, channel);
+                transmittance = transmittance * ((tr_pdf > 0.f) ? tr / tr_pdf : V3(0.f));
+            }
+            if ((mei.t > remaining_dist) && mei.valid()) total_dist = ds.dist;
+            if (mei.t > remaining_dist) mei.t = kInf;
+            escaped_medium = !mei.valid();
+            active_medium = mei.valid();
+            if (active_medium) {
+                total_dist += mei.t;
+                ray.o = mei.p;
+                si.t = si.t - mei.t;
+                if (spectral) transmittance = transmittance * mei.sigma_n;
+                else transmittance = transmittance * (mei.sigma_n / mei.combined);
+            }
+        }
+        bool intersect = active_surface && needs_intersection;
+        if (intersect) { n_shadow++; Hit h = trace<false>(sc, ray, stack); si = compute_si(sc, ray, h); needs_intersection = false; }
+        active_surface = active_surface || escaped_medium;
+        if (active_surface) total_dist += si.t;
+        active_surface = active_surface && si.valid && !active_medium;
+        if (active_surface) {
+            transmittance = transmittance * bsdf_null_transmission(sc, sc.shapes[si.shape].bsdf);
+            ray = spawn_ray(si.p, si.n, ray.d);
+        }
+        ray.maxt = remaining_dist;
+        needs_intersection = needs_intersection || active_surface;
+        active = (active_medium || active_surface) && any_nonzero(transmittance);
+        if (active_surface) { const DShape sd = sc.shapes[si.shape]; if (is_medium_transition(sd)) medium = target_medium(sd, ray.d, si.n); }
+    }
+    return transmittance * emitter_val;
+}
+
+// One trip of volpath's while_loop (src/integrators/volpath.cpp:170-391).
+// Returns true when the path survives.
+DEV bool volpath_iteration(const DScene &sc, const DRenderParams &rp, PathState &s, PCG32 &rng, int *stack, uint32_t &n_shadow) {
+    uint32_t depth = s.flags & PF_DEPTH_MASK;
+    int medium = (int) ((s.flags & PF_MEDIUM_MASK) >> PF_MEDIUM_SHIFT) - 1;
+    const uint32_t channel = (s.flags >> PF_CHANNEL_SHIFT) & 3u;
+    bool specular_chain = (s.flags & PF_SPECULAR) != 0, valid_ray = (s.flags & PF_VALID) != 0;
+    const uint32_t max_depth = (uint32_t) rp.max_depth;
+    V3 throughput = s.tp, result = s.res;
+    float eta = s.eta;
+    Ray ray; ray.o = s.o; ray.d = s.d; ray.maxt = s.maxt;
+    auto commit = [&]() {
+        s.tp = throughput; s.res = result; s.eta = eta; s.o = ray.o; s.d = ray.d; s.maxt = ray.maxt;
+        s.flags = (depth & PF_DEPTH_MASK) | ((uint32_t) (medium + 1) << PF_MEDIUM_SHIFT) | (channel << PF_CHANNEL_SHIFT) |
+                  (specular_chain ? PF_SPECULAR : 0u) | (valid_ray ? PF_VALID : 0u);
+    };
+    // ---- termination (volpath.cpp:190-203)
+    bool active = any_nonzero(throughput);
+    float q = fmin_(max3(throughput) * sqr(eta), .95f);
+    bool perform_rr = depth > (uint32_t) rp.rr_depth;
+    if (active) { float u = rng.next(); active = (u < q) || !perform_rr; }
+    if (perform_rr) throughput = throughput * rcp(q);
+    active = active && depth < max_depth;
+    if (!active) { commit(); return false; }
+
+    bool active_medium = medium >= 0, active_surface = !active_medium;
+    bool act_medium_scatter = false, escaped_medium = false;
+    MI mei; mei.t = kInf;
+    SI si; si.valid = false; si.t = kInf;
+    if (active_medium) {
+        const DMedium M = sc.media[medium];
+        mei = medium_sample_interaction(M, ray, rng.next(), channel);
+        if (mei.valid()) ray.maxt = mei.t;
+        { Hit h = trace<false>(sc, ray, stack); si = compute_si(sc, ray, h); }
+        if (si.t < mei.t) mei.t = kInf;
+        if (M.has_spectral_extinction) {
+            float t = fmin_(mei.t, si.t) - mei.mint;
+            V3 tr(m_exp(-t * mei.combined.x), m_exp(-t * mei.combined.y), m_exp(-t * mei.combined.z));
+            V3 pdf = (si.t < mei.t) ? tr : tr * mei.combined;
+            float tr_pdf = idx3(pdf, channel);
+            throughput = throughput * ((tr_pdf > 0.f) ? tr / tr_pdf : V3(0.f));
+        }
+        escaped_medium = !mei.valid();
+        active_medium = mei.valid();
+        if (active_medium) {
+            (void) rng.next();                        // null/real collision draw (sigma_n = 0: always real)
+            act_medium_scatter = true;
+            depth += 1;
+            s.lp = mei.p;
+        }
+    }
+    active = active && depth < max_depth;
+    act_medium_scatter = act_medium_scatter && active;
+    if (act_medium_scatter) {
+        const DMedium M = sc.media[medium];
+        if (M.has_spectral_extinction) throughput = throughput * (mei.sigma_s / mean3(mei.sigma_t / mei.combined));
+        else throughput = throughput * (mei.sigma_s / mei.sigma_t);
+        bool sample_emitters = M.sample_emitters != 0;
+        valid_ray = true;
+        specular_chain = !sample_emitters;
+        if (sample_emitters) {
+            DirSample ds;
+            V3 emitted = volpath_sample_emitter(sc, rng, mei.p, V3(0.f), false, 0, V3(0.f), medium, channel, &ds, stack, n_shadow);
+            float phase_val = phase_eval(M, mei.wi, ds.d);
+            V3 c = throughput * phase_val * emitted * mis_weight(ds.pdf, ds.delta ? 0.f : phase_val);
+            result = result + c;
+        }
+        (void) rng.next();
+        float s2x = rng.next(), s2y = rng.next();
+        V3 wo; float phase_pdf; phase_sample(M, mei.wi, s2x, s2y, &wo, &phase_pdf);
+        if (phase_pdf > 0.f) {
+            ray = spawn_ray(mei.p, V3(0.f), wo);
+            s.last_pdf = phase_pdf;
+        }
+    }
+    // ---- surface interactions
+    active_surface = active_surface || escaped_medium;
+    bool intersect = active_surface && !escaped_medium;   // medium lanes already hold si
+    if (intersect) { Hit h = trace<false>(sc, ray, stack); si = compute_si(sc, ray, h); }
+    if (active_surface) {
+        if (rp.hide_emitters && depth == 0 && intersect) {         // volpath.cpp:304-320, integrator.cpp:96-123
+            bool skip = si.valid && sc.shapes[si.shape].emitter >= 0;
+            if (skip) {
+                Ray r2 = spawn_ray(si.p, si.n, ray.d);
+                bool a = true; Hit h; h.prim = 0xffffffffu; h.t = kInf; h.u = h.v = 0.f;
+                while (a) {
+                    h = trace<false>(sc, r2, stack);
+                    a = h.prim != 0xffffffffu && sc.shapes[sc.face_shape[h.prim]].emitter >= 0;
+                    if (a) { SI s2 = compute_si(sc, r2, h); r2 = spawn_ray(s2.p, s2.n, r2.d); }
+                }
+                si = compute_si(sc, r2, h);
+            }
+        }
+        bool count_direct = (depth == 0) || specular_chain;
+        int emitter = si_emitter(sc, si);
+        bool active_e = emitter >= 0 && !(depth == 0 && rp.hide_emitters);
+        if (active_e) {
+            float emitter_pdf = 1.f;
+            if (!count_direct) emitter_pdf = pdf_emitter_direction(sc, s.lp, si, emitter);
+            V3 emitted = emitter_eval(sc, emitter, si);
+            V3 contrib = count_direct ? throughput * emitted : throughput * mis_weight(s.last_pdf, emitter_pdf) * emitted;
+            result = result + contrib;
+        }
+    }
+    active_surface = active_surface && si.valid;
+    if (active_surface) {
+        const DShape sd = sc.shapes[si.shape];
+        int b = sd.bsdf;
+        int flags = sc.bsdfs[b].flags;
+        bool active_e = (flags & F_SMOOTH) && (depth + 1 < max_depth);
+        if (active_e) {
+            DirSample ds;
+            V3 emitted = volpath_sample_emitter(sc, rng, si.p, si.n, true, si.shape, si.n, medium, channel, &ds, stack, n_shadow);
+            V3 wo = si.sh.to_local(ds.d);
+            V3 bsdf_val = bsdf_eval(sc, b, si, wo);
+            float bpdf = bsdf_pdf(sc, b, si, wo);
+            V3 c = throughput * bsdf_val * mis_weight(ds.pdf, ds.delta ? 0.f : bpdf) * emitted;
+            result = result + c;
+        }
+        float s1 = rng.next(), s2x = rng.next(), s2y = rng.next();
+        BSDFSample bs; V3 bsdf_val;
+        bsdf_sample(sc, b, si, s1, s2x, s2y, &bs, &bsdf_val);
+        throughput = throughput * bsdf_val;
+        eta *= bs.eta;
+        ray = spawn_ray(si.p, si.n, si.sh.to_world(bs.wo));
+        bool non_null = !(bs.type & F_NULL);
+        if (non_null) { depth += 1; s.lp = si.p; s.last_pdf = bs.pdf; valid_ray = true; }
+        specular_chain = specular_chain || (non_null && (bs.type & F_DELTA));
+        specular_chain = specular_chain && !(bs.type & F_SMOOTH);
+        if (is_medium_transition(sd)) medium = target_medium(sd, ray.d, si.n);
+    }
+    active = active && (active_surface || active_medium);
+    commit();
+    return active;
+}
+
+// One trip of path's while_loop (src/integrators/path.cpp:194-338); the
+// ray_intersect_preliminary of the previous trip (:332-337, or :164-169 for the
+// first one) is the trace at the top.
+DEV bool path_iteration(const DScene &sc, const DRenderParams &rp, PathState &s, PCG32 &rng, int *stack, uint32_t &n_shadow) {
+    uint32_t depth = s.flags & PF_DEPTH_MASK;
+    bool prev_bsdf_delta = (s.flags & PF_SPECULAR) != 0, valid_ray = (s.flags & PF_VALID) != 0;
+    const uint32_t max_depth = (uint32_t) rp.max_depth;
+    V3 throughput = s.tp, result = s.res;
+    float eta = s.eta;
+    Ray ray; ray.o = s.o; ray.d = s.d; ray.maxt = s.maxt;
+    auto commit = [&]() {
+        s.tp = throughput; s.res = result; s.eta = eta; s.o = ray.o; s.d = ray.d; s.maxt = ray.maxt;
+        s.flags = (depth & PF_DEPTH_MASK) | (prev_bsdf_delta ? PF_SPECULAR : 0u) | (valid_ray ? PF_VALID : 0u);
+    };
+    if (max_depth == 0) { commit(); return false; }
+    Hit pi = trace<false>(sc, ray, stack);
+    if (rp.hide_emitters && depth == 0) {                          // path.cpp:178-192
+        bool skip = pi.prim != 0xffffffffu && sc.shapes[sc.face_shape[pi.prim]].emitter >= 0;
+        if (skip) {
+            SI s0 = compute_si(sc, ray, pi);
+            Ray r2 = spawn_ray(s0.p, s0.n, ray.d);
+            bool a = true; Hit h; h.prim = 0xffffffffu; h.t = kInf; h.u = h.v = 0.f;
+            while (a) {
+                h = trace<false>(sc, r2, stack);
+                a = h.prim != 0xffffffffu && sc.shapes[sc.face_shape[h.prim]].emitter >= 0;
+                if (a) { SI s2 = compute_si(sc, r2, h); r2 = spawn_ray(s2.p, s2.n, r2.d); }
+            }
+            pi = h; ray = r2;
+        }
+    }
+    SI si = compute_si(sc, ray, pi);
+    int emitter = si_emitter(sc, si);
+    if (emitter >= 0) {
+        float em_pdf = 0.f;
+        if (!prev_bsdf_delta) em_pdf = pdf_emitter_direction(sc, s.lp, si, emitter);
+        float mis_bsdf = mis_weight(s.last_pdf, em_pdf);
+        V3 em = (s.last_pdf > 0.f) ? emitter_eval(sc, emitter, si) : V3(0.f);
+        em = em * mis_bsdf;
+        result = V3(fma_(throughput.x, em.x, result.x), fma_(throughput.y, em.y, result.y), fma_(throughput.z, em.z, result.z));
+    }
+    bool active_next = (depth + 1 < max_depth) && si.valid;
+    if (!active_next) { valid_ray = valid_ray || (emitter >= 0 && !rp.hide_emitters); commit(); return false; }
+    const DShape sd = sc.shapes[si.shape];
+    int b = sd.bsdf;
+    bool active_em = (sc.bsdfs[b].flags & F_SMOOTH) != 0;
+    DirSample ds; ds.pdf = 0.f; ds.delta = false; ds.d = V3(0.f);
+    V3 em_weight(0.f), wo(0.f);
+    if (active_em) {
+        float sx = rng.next(), sy = rng.next();
+        em_weight = sample_emitter_direction(sc, si.p, sx, sy, &ds);
+        if (ds.pdf != 0.f) {                                       // scene.cpp:361-365 test_visibility
+            Ray sr = spawn_ray_to(si.p, si.n, ds.p);
+            n_shadow++;
+            Hit h = trace<true>(sc, sr, stack);
+            if (h.prim != 0xffffffffu) { em_weight = V3(0.f); ds.pdf = 0.f; }
+        }
+        active_em = ds.pdf != 0.f;
+        wo = si.sh.to_local(ds.d);
+    }
+    float s1 = rng.next(), s2x = rng.next(), s2y = rng.next();
+    V3 bsdf_val = bsdf_eval(sc, b, si, wo);
+    float bpdf = bsdf_pdf(sc, b, si, wo);
+    BSDFSample bs; V3 bsdf_weight;
+    bsdf_sample(sc, b, si, s1, s2x, s2y, &bs, &bsdf_weight);
+    if (active_em) {
+        float mis_em = ds.delta ? 1.f : mis_weight(ds.pdf, bpdf);
+        V3 c = bsdf_val * em_weight * mis_em;
+        result = V3(fma_(throughput.x, c.x, result.x), fma_(throughput.y, c.y, result.y), fma_(throughput.z, c.z, result.z));
+    }
+    ray = spawn_ray(si.p, si.n, si.sh.to_world(bs.wo));
+    throughput = throughput * bsdf_weight;
+    eta *= bs.eta;
+    valid_ray = valid_ray || !(bs.type & F_NULL);
+    s.lp = si.p; s.last_pdf = bs.pdf; prev_bsdf_delta = (bs.type & F_DELTA) != 0;
+    depth += 1;
+    float tmax = max3(throughput);
+    float rr_prob = fmin_(tmax * sqr(eta), .95f);
+    bool rr_active = depth >= (uint32_t) rp.rr_depth, rr_continue = rng.next() < rr_prob;
+    if (rr_active) throughput = throughput * rcp(rr_prob);
+    bool active = active_next && (!rr_active || rr_continue) && (tmax != 0.f);
+    commit();
+    return active;
+}
+
+template <int INTEGRATOR>
+__global__ void __launch_bounds__(LRT_BLOCK)
+k_iterate(DScene sc, DRenderParams rp, DPathStreams qin, DPathStreams qout, DCounters *__restrict__ cnt, uint32_t n_in,
+          float *__restrict__ film, float *__restrict__ sample_out, uint64_t sample_base) {
+    __shared__ int s_stack[LRT_STACK * LRT_BLOCK];
+    __shared__ uint32_t s_wave_count[LRT_BLOCK / 64];
+    __shared__ uint32_t s_base;
+    __shared__ uint32_t s_shadow;
+    const uint32_t tid = threadIdx.x, i = blockIdx.x * LRT_BLOCK + tid;
+    const uint32_t wave = tid >> 6, lane_in_wave = tid & 63u;
+    if (tid == 0) s_shadow = 0;
+    bool alive = false;
+    PathState s;
+    uint32_t n_shadow = 0;
+    if (i < n_in) {
+        load_state(qin, i, s);
+        PCG32 rng; rng.state = s.rng_state; rng.inc = lane_rng_inc(rp.seed_value, s.lane);
+        if (INTEGRATOR == LRT_INTEGRATOR_PATH) alive = path_iteration(sc, rp, s, rng, s_stack + tid, n_shadow);
+        else alive = volpath_iteration(sc, rp, s, rng, s_stack + tid, n_shadow);
+        s.rng_state = rng.state;
+        if (!alive) finish_path(sc, rp, film, sample_out, sample_base, s.lane, s.res, (s.flags & PF_VALID) != 0);
+    }
+    // ---- compaction: ballot + popcount inside the wave, one queue atomic per workgroup
+    const unsigned long long m = __ballot(alive);
+    const uint32_t wcount = (uint32_t) __popcll(m);
+    const uint32_t wprefix = (uint32_t) __popcll(m & ((1ull << lane_in_wave) - 1ull));
+    if (lane_in_wave == 0) s_wave_count[wave] = wcount;
+    // wave-level reduction of the shadow-ray counter
+    for (int off = 32; off > 0; off >>= 1) n_shadow += __shfl_down(n_shadow, off);
+    __syncthreads();
+    if (lane_in_wave == 0 && n_shadow) atomicAdd(&s_shadow, n_shadow);
+    if (tid == 0) {
+        uint32_t total = 0;
+        for (int w = 0; w < LRT_BLOCK / 64; ++w) total += s_wave_count[w];
+        s_base = total ? atomicAdd(&cnt->n_out, total) : 0u;
+    }
+    __syncthreads();
+    if (alive) {
+        uint32_t slot = s_base + wprefix;
+        for (uint32_t w = 0; w < wave; ++w) slot += s_wave_count[w];
+        store_state(qout, slot, s);
+    }
+    if (tid == 0 && s_shadow) atomicAdd(&cnt->n_shadow, (unsigned long long) s_shadow);
+}
+
+// src/films/hdrfilm.cpp:306-410
+__global__ void k_develop(DFilm F, const float *__restrict__ film, float *__restrict__ image, uint32_t n_pixels) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pixels) return;
+    int C = F.channels, T = F.has_alpha ? 4 : 3;
+    float w = film[(size_t) i * C + C - 1]; if (w == 0.f) w = 1.f;
+    for (int c = 0; c < T; ++c) image[(size_t) i * T + c] = film[(size_t) i * C + c] / w;
+}
+
+template <bool ANY_HIT>
+__global__ void __launch_bounds__(LRT_BLOCK)
+k_trace(DScene sc, const float *ox, const float *oy, const float *oz, const float *dx, const float *dy, const float *dz, const float *tmax,
+        float *t, float *u, float *v, uint32_t *prim, uint32_t n) {
+    __shared__ int s_stack[LRT_STACK * LRT_BLOCK];
+    uint32_t i = blockIdx.x * LRT_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    Ray r; r.o = V3(ox[i], oy[i], oz[i]); r.d = V3(dx[i], dy[i], dz[i]); r.maxt = tmax[i];
+    Hit h = trace<ANY_HIT>(sc, r, s_stack + threadIdx.x);
+    if (ANY_HIT) { t[i] = h.prim != 0xffffffffu ? 0.f : kInf; return; }
+    t[i] = h.t; if (u) u[i] = h.u; if (v) v[i] = h.v; if (prim) prim[i] = h.prim;
+}
+
+} // namespace lrt

@@ -1,0 +1,1020 @@
+/*
+ * orc_render.cpp -- the sample loop of the CPU oracle: RNG, sensor, BSDFs,
+ * phase functions, media, emitters, the `path` and `volpath` integrators and
+ * the film.  TEST INFRASTRUCTURE ONLY (see orc.h).  Every function cites the
+ * reference lines it restates (paths relative to the reference tree).
+ */
+#include "orc_scene.h"
+#include <thread>
+#include <mutex>
+#include <cstdio>
+#include <algorithm>
+
+namespace orc {
+
+/* ------------------------------------------------------------------- RNG */
+/* include/mitsuba/core/random.h:76-91 */
+static inline void tea32(uint32_t v0, uint32_t v1, int rounds, uint32_t *o0, uint32_t *o1) {
+    uint32_t sum = 0;
+    for (int i = 0; i < rounds; ++i) {
+        sum += 0x9e3779b9u;
+        v0 += ((v1 << 4) + 0xa341316cu) ^ (v1 + sum) ^ ((v1 >> 5) + 0xc8013ea4u);
+        v1 += ((v0 << 4) + 0xad90777du) ^ (v0 + sum) ^ ((v0 >> 5) + 0x7e95761eu);
+    }
+    *o0 = v0; *o1 = v1;
+}
+
+/* Dr.Jit 1.3.1 drjit/random.h PCG32 (un-vendored): O'Neill's PCG32-XSH-RR */
+struct PCG32 {
+    uint64_t state, inc;
+    void seed(uint64_t initstate, uint64_t initseq) {
+        state = 0; inc = (initseq << 1) | 1u; next_u32(); state += initstate; next_u32();
+    }
+    uint32_t next_u32() {
+        uint64_t old = state;
+        state = old * 0x5851f42d4c957f2dULL + inc;
+        uint32_t xs = (uint32_t) (((old >> 18) ^ old) >> 27), rot = (uint32_t) (old >> 59);
+        return (xs >> rot) | (xs << ((0u - rot) & 31u));
+    }
+    float next() { return u2f((next_u32() >> 9) | 0x3f800000u) - 1.f; }
+};
+
+/* src/render/sampler.cpp:129-148 (JIT branch): per-lane stream */
+static inline PCG32 lane_rng(uint32_t base_seed, uint32_t seed, uint32_t lane) {
+    uint32_t v0, v1; tea32(base_seed + seed, lane, 4, &v0, &v1);
+    PCG32 r; r.seed(v0, v1); return r;
+}
+
+/* ---------------------------------------------------------------- sensor */
+/* src/sensors/perspective.cpp:239-279 (differentials unused: volpath.cpp:107, no ray-differential consumers) */
+static Ray sample_ray(const Scene &S, float px, float py) {
+    V3 near_p = xform_point_proj(S.sample_to_camera, V3(px + 0.f, py + 0.f, 0.f));
+    V3 d = normalize(near_p);
+    Ray r;
+    r.o = V3(S.cam_to_world.m[3], S.cam_to_world.m[7], S.cam_to_world.m[11]);
+    r.d = xform_vec(S.cam_to_world, d);
+    float inv_z = rcp(d.z), near_t = S.d.sensor.near_clip * inv_z, far_t = S.d.sensor.far_clip * inv_z;
+    r.o = r.o + r.d * near_t;
+    r.maxt = far_t - near_t;
+    return r;
+}
+
+/* -------------------------------------------------------------- warping */
+/* include/mitsuba/core/warp.h:54-92 */
+static V2 square_to_uniform_disk_concentric(float sx, float sy) {
+    float x = fmaf(2.f, sx, -1.f), y = fmaf(2.f, sy, -1.f);
+    bool is_zero = (x == 0.f) && (y == 0.f), q13 = fabsf(x) < fabsf(y);
+    float r = q13 ? y : x, rp = q13 ? x : y;
+    float phi = 0.25f * kPi * rp / r;
+    if (q13) phi = 0.5f * kPi - phi;
+    if (is_zero) phi = 0.f;
+    float s, c; m_sincos(phi, &s, &c);
+    return { r * c, r * s };
+}
+/* include/mitsuba/core/warp.h:412-420 */
+static V3 square_to_cosine_hemisphere(float sx, float sy) {
+    V2 p = square_to_uniform_disk_concentric(sx, sy);
+    float z = safe_sqrt(1.f - fmaf(p.x, p.x, p.y * p.y));
+    return V3(p.x, p.y, z);
+}
+/* include/mitsuba/core/warp.h:250-256 */
+static V3 square_to_uniform_sphere(float sx, float sy) {
+    float z = fmaf(-2.f, sy, 1.f), r = safe_sqrt(fmaf(-z, z, 1.f));
+    float s, c; m_sincos(2.f * kPi * sx, &s, &c);
+    return V3(r * c, r * s, z);
+}
+
+/* ---------------------------------------------------------- interactions */
+/* include/mitsuba/render/interaction.h:140-168 */
+static inline V3 offset_p(V3 p, V3 n, V3 d) {
+    float mag = (1.f + max3(abs3(p))) * kRayEpsilon;
+    mag = mulsign(mag, dot(n, d));
+    return fma3(n, mag, p);
+}
+static inline Ray spawn_ray(V3 p, V3 n, V3 d) { Ray r; r.o = offset_p(p, n, d); r.d = d; r.maxt = kLargest; return r; }
+static inline Ray spawn_ray_to(V3 p, V3 n, V3 t) {
+    Ray r; r.o = offset_p(p, n, t - p);
+    V3 d = t - r.o; float dist = norm(d);
+    r.d = d / dist; r.maxt = dist * (1.f - kShadowEpsilon);
+    return r;
+}
+
+/* -------------------------------------------------------------- textures */
+static V3 tex_eval(const Scene &S, int tex, const SI &si) {
+    const lrt_texture_desc &T = S.textures[tex];
+    if (T.type == LRT_TEX_RGB) return V3(T.color0[0], T.color0[1], T.color0[2]);
+    if (T.type == LRT_TEX_CHECKERBOARD) {       /* src/textures/checkerboard.cpp:70-88 */
+        float u = fmaf(T.to_uv[1], si.uv.y, fmaf(T.to_uv[0], si.uv.x, T.to_uv[2]));
+        float v = fmaf(T.to_uv[4], si.uv.y, fmaf(T.to_uv[3], si.uv.x, T.to_uv[5]));
+        bool mx = u - floorf(u) > .5f, my = v - floorf(v) > .5f;
+        return (mx == my) ? V3(T.color0[0], T.color0[1], T.color0[2]) : V3(T.color1[0], T.color1[1], T.color1[2]);
+    }
+    return V3(0.f);
+}
+
+/* src/textures/bitmap.cpp:509-578 eval_1_grad (bilinear, repeat wrap; texel fetch
+   order of Dr.Jit Texture::eval_fetch: (x0,y0),(x1,y0),(x0,y1),(x1,y1)) */
+static V2 tex_eval_1_grad(const Scene &S, int tex, const SI &si) {
+    const lrt_texture_desc &T = S.textures[tex];
+    if (T.type != LRT_TEX_BITMAP) return { 0.f, 0.f };
+    float u = fmaf(T.to_uv[1], si.uv.y, fmaf(T.to_uv[0], si.uv.x, T.to_uv[2]));
+    float v = fmaf(T.to_uv[4], si.uv.y, fmaf(T.to_uv[3], si.uv.x, T.to_uv[5]));
+    int w = T.width, h = T.height;
+    float fx = fmaf(u, (float) w, -0.5f), fy = fmaf(v, (float) h, -0.5f);
+    int ix = (int) floorf(fx), iy = (int) floorf(fy);
+    float w1x = fx - (float) ix, w1y = fy - (float) iy, w0x = 1.f - w1x, w0y = 1.f - w1y;
+    auto wrap = [](int i, int n) { int r = i % n; return r < 0 ? r + n : r; };
+    int x0 = wrap(ix, w), x1 = wrap(ix + 1, w), y0 = wrap(iy, h), y1 = wrap(iy + 1, h);
+    auto fetch = [&](int x, int y) {
+        const float *p = &T.data[((size_t) y * w + x) * T.channels];
+        return T.channels == 1 ? p[0] : luminance(V3(p[0], p[1], p[2]));
+    };
+    float f00 = fetch(x0, y0), f10 = fetch(x1, y0), f01 = fetch(x0, y1), f11 = fetch(x1, y1);
+    float dx = fmaf(w0y, f10 - f00, w1y * (f11 - f01)), dy = fmaf(w0x, f01 - f00, w1x * (f11 - f10));
+    float du = T.to_uv[0] * dx + T.to_uv[3] * dy, dv = T.to_uv[1] * dx + T.to_uv[4] * dy;
+    return { (float) w * du, (float) h * dv };
+}
+
+/* ----------------------------------------------------------------- BSDFs */
+enum { F_DELTA = 1, F_SMOOTH = 2, F_NULL = 4 };   /* subset of BSDFFlags used by the integrators */
+struct BSDFSample { V3 wo; float pdf, eta; int type; };
+
+static int bsdf_flags(const Scene &S, int b) {
+    const lrt_bsdf_desc &B = S.bsdfs[b];
+    switch (B.type) {
+        case LRT_BSDF_DIFFUSE: return F_SMOOTH;
+        case LRT_BSDF_DIELECTRIC: return F_DELTA;
+        case LRT_BSDF_BUMPMAP: return bsdf_flags(S, B.nested);
+        default: return F_NULL;
+    }
+}
+
+/* include/mitsuba/render/fresnel.h:35-73 */
+static void fresnel(float cos_theta_i, float eta, float *r, float *cos_theta_t, float *eta_it, float *eta_ti) {
+    bool outside = cos_theta_i >= 0.f;
+    float rcp_eta = rcp(eta);
+    *eta_it = outside ? eta : rcp_eta; *eta_ti = outside ? rcp_eta : eta;
+    float cos_theta_t_sqr = fmaf(-fmaf(-cos_theta_i, cos_theta_i, 1.f), *eta_ti * *eta_ti, 1.f);
+    float cti = fabsf(cos_theta_i), ctt = safe_sqrt(cos_theta_t_sqr);
+    bool index_matched = eta == 1.f, special = index_matched || cti == 0.f;
+    float r_sc = index_matched ? 0.f : 1.f;
+    float a_s = fmaf(-*eta_it, ctt, cti) / fmaf(*eta_it, ctt, cti);
+    float a_p = fmaf(-*eta_it, cti, ctt) / fmaf(*eta_it, cti, ctt);
+    float rr = 0.5f * (sqr(a_s) + sqr(a_p));
+    if (special) rr = r_sc;
+    *r = rr; *cos_theta_t = mulsign_neg(ctt, cos_theta_i);
+}
+
+static void bsdf_sample(const Scene &S, int b, const SI &si, float s1, float s2x, float s2y, BSDFSample *bs, V3 *weight);
+static V3 bsdf_eval(const Scene &S, int b, const SI &si, V3 wo);
+static float bsdf_pdf(const Scene &S, int b, const SI &si, V3 wo);
+
+/* src/bsdfs/bumpmap.cpp:226-251 frame() */
+static Frame bump_frame(const Scene &S, const lrt_bsdf_desc &B, const SI &si) {
+    V2 g = tex_eval_1_grad(S, B.texture, si);
+    float gx = B.scale * g.x, gy = B.scale * g.y;
+    V3 dp_du = fma3(si.sh.n, gx - dot(si.sh.n, si.dp_du), si.dp_du);
+    V3 dp_dv = fma3(si.sh.n, gy - dot(si.sh.n, si.dp_dv), si.dp_dv);
+    Frame r;
+    r.n = normalize(cross(dp_du, dp_dv));
+    if (dot(si.n, r.n) < 0.f) r.n = r.n * -1.f;
+    r.n = si.sh.to_local(r.n);
+    if (si.wi.z * dot(si.wi, r.n) <= 0.f) r.n = V3(-r.n.x, -r.n.y, r.n.z);   /* flip_invalid_normals */
+    r.s = normalize(fma3(r.n, -dot(r.n, si.dp_du), si.dp_du));
+    r.t = cross(r.n, r.s);
+    return r;
+}
+/* include/mitsuba/core/frame.h:80-83, src/bsdfs/normalmap_helpers.h:20-25 */
+static float tan_theta_2(V3 v) { float t = fmaf(-v.z, v.z, 1.f); return fmaxf(t, 0.f) / sqr(v.z); }
+static float shadow_terminator(V3 pn, V3 wo) {
+    float alpha2 = fminf(0.125f * tan_theta_2(pn), 1.f);
+    return 2.f / (1.f + sqrtf(1.f + alpha2 * tan_theta_2(wo)));
+}
+
+static void bsdf_sample(const Scene &S, int b, const SI &si, float s1, float s2x, float s2y, BSDFSample *bs, V3 *weight) {
+    const lrt_bsdf_desc &B = S.bsdfs[b];
+    bs->wo = V3(0.f); bs->pdf = 0.f; bs->eta = 0.f; bs->type = 0; *weight = V3(0.f);   /* dr::zeros<BSDFSample3f> */
+    switch (B.type) {
+        case LRT_BSDF_DIFFUSE: {                 /* src/bsdfs/diffuse.cpp sample() */
+            float cti = si.wi.z;
+            if (!(cti > 0.f)) return;
+            bs->wo = square_to_cosine_hemisphere(s2x, s2y);
+            bs->pdf = kInvPi * bs->wo.z; bs->eta = 1.f; bs->type = F_SMOOTH;
+            if (bs->pdf > 0.f) *weight = tex_eval(S, B.reflectance, si);
+            return;
+        }
+        case LRT_BSDF_DIELECTRIC: {              /* src/bsdfs/dielectric.cpp:230-367 */
+            float r_i, ctt, eta_it, eta_ti;
+            fresnel(si.wi.z, B.eta, &r_i, &ctt, &eta_it, &eta_ti);
+            float t_i = 1.f - r_i;
+            bool sel_r = s1 <= r_i;
+            bs->pdf = sel_r ? r_i : t_i;
+            bs->type = F_DELTA;
+            bs->wo = sel_r ? V3(-si.wi.x, -si.wi.y, si.wi.z) : V3(-eta_ti * si.wi.x, -eta_ti * si.wi.y, ctt);
+            bs->eta = sel_r ? 1.f : eta_it;
+            *weight = V3(1.f);
+            if (!sel_r) *weight = *weight * sqr(eta_ti);
+            return;
+        }
+        case LRT_BSDF_BUMPMAP: {                 /* src/bsdfs/bumpmap.cpp:138-162 */
+            SI psi = si;
+            psi.sh = bump_frame(S, B, si);
+            psi.wi = psi.sh.to_local(si.wi);
+            V3 w; bsdf_sample(S, B.nested, psi, s1, s2x, s2y, bs, &w);
+            bool active = any_nonzero(w);
+            V3 pwo = psi.sh.to_world(bs->wo);
+            active = active && (bs->wo.z * pwo.z > 0.f);
+            bs->wo = pwo;
+            w = w * shadow_terminator(psi.sh.n, bs->wo);
+            *weight = active ? w : V3(0.f);
+            return;
+        }
+        default: {                               /* src/bsdfs/null.cpp sample() */
+            bs->wo = -si.wi; bs->type = F_NULL; bs->eta = 1.f; bs->pdf = 1.f; *weight = V3(1.f);
+            return;
+        }
+    }
+}
+
+static V3 bsdf_eval(const Scene &S, int b, const SI &si, V3 wo) {
+    const lrt_bsdf_desc &B = S.bsdfs[b];
+    if (B.type == LRT_BSDF_DIFFUSE) {             /* src/bsdfs/diffuse.cpp eval() */
+        if (!(si.wi.z > 0.f && wo.z > 0.f)) return V3(0.f);
+        return tex_eval(S, B.reflectance, si) * kInvPi * wo.z;
+    }
+    if (B.type == LRT_BSDF_BUMPMAP) {             /* src/bsdfs/bumpmap.cpp:164-183 */
+        SI psi = si; psi.sh = bump_frame(S, B, si); psi.wi = psi.sh.to_local(si.wi);
+        V3 pwo = psi.sh.to_local(wo);
+        if (!(wo.z * pwo.z > 0.f)) return V3(0.f);
+        return bsdf_eval(S, B.nested, psi, pwo) * shadow_terminator(psi.sh.n, wo);
+    }
+    return V3(0.f);
+}
+static float bsdf_pdf(const Scene &S, int b, const SI &si, V3 wo) {
+    const lrt_bsdf_desc &B = S.bsdfs[b];
+    if (B.type == LRT_BSDF_DIFFUSE)
+        return (si.wi.z > 0.f && wo.z > 0.f) ? kInvPi * wo.z : 0.f;
+    if (B.type == LRT_BSDF_BUMPMAP) {
+        SI psi = si; psi.sh = bump_frame(S, B, si); psi.wi = psi.sh.to_local(si.wi);
+        V3 pwo = psi.sh.to_local(wo);
+        if (!(wo.z * pwo.z > 0.f)) return 0.f;
+        return bsdf_pdf(S, B.nested, psi, pwo);
+    }
+    return 0.f;
+}
+/* src/render/bsdf.cpp:33-36, src/bsdfs/null.cpp eval_null_transmission */
+static float bsdf_null_transmission(const Scene &S, int b) {
+    const lrt_bsdf_desc &B = S.bsdfs[b];
+    if (B.type == LRT_BSDF_BUMPMAP) return 0.f;   /* BumpMap does not forward it: base-class 0 */
+    return B.type == LRT_BSDF_NULL ? 1.f : 0.f;
+}
+
+/* -------------------------------------------------------------- emitters */
+struct DirSample { V3 p, n, d; float pdf, dist; bool delta; int emitter; };
+
+/* src/emitters/envmap.cpp:528-560 eval_spectrum (RGB) */
+static V3 env_eval_uv(const Scene &S, float u, float v) {
+    const lrt_emitter_desc &E = S.emitters[S.env];
+    uint32_t rx = S.env_w, ry = S.env_h;
+    u -= .5f / (float) (rx - 1u);
+    u -= floorf(u); v -= floorf(v);
+    u *= (float) (rx - 1u); v *= (float) (ry - 1u);
+    uint32_t px = std::min((uint32_t) u, rx - 2u), py = std::min((uint32_t) v, ry - 2u);
+    float w1x = u - (float) px, w1y = v - (float) py, w0x = 1.f - w1x, w0y = 1.f - w1y;
+    uint32_t idx = py * rx + px;
+    auto px3 = [&](uint32_t i) { return V3(S.env_data[3 * i], S.env_data[3 * i + 1], S.env_data[3 * i + 2]); };
+    V3 v00 = px3(idx), v10 = px3(idx + 1), v01 = px3(idx + rx), v11 = px3(idx + rx + 1);
+    auto f3 = [](float a, V3 x, V3 y) { return V3(fmaf(a, x.x, y.x), fmaf(a, x.y, y.y), fmaf(a, x.z, y.z)); };
+    V3 v0 = f3(w0x, v00, v10 * w1x), v1 = f3(w0x, v01, v11 * w1x), vv = f3(w0y, v0, v1 * w1y);
+    return vv * E.scale;
+}
+static V3 emitter_eval_env(const Scene &S, V3 dir_world) {   /* dir_world = -si.wi of an invalid si */
+    const lrt_emitter_desc &E = S.emitters[S.env];
+    if (E.type == LRT_EMITTER_CONSTANT) return V3(E.radiance[0], E.radiance[1], E.radiance[2]);
+    /* src/emitters/envmap.cpp:353-362 eval */
+    V3 v = xform_vec(S.env_to_local, dir_world);
+    float uu = m_atan2(v.x, -v.z) * kInvTwoPi, vv = safe_acos(v.y) * kInvPi;
+    return env_eval_uv(S, uu, vv);
+}
+/* src/emitters/area.cpp eval(): radiance & (cos_theta(wi) > 0) */
+static V3 emitter_eval_area(const Scene &S, int e, const SI &si) {
+    const lrt_emitter_desc &E = S.emitters[e];
+    return (si.wi.z > 0.f) ? V3(E.radiance[0], E.radiance[1], E.radiance[2]) : V3(0.f);
+}
+
+/* Scene::sample_emitter_direction (src/render/scene.cpp:333-383) without the
+   visibility test; returns the emitter weight (radiance / pdf). */
+static V3 sample_emitter_direction(const Scene &S, V3 ref_p, float sx, float sy, DirSample *ds) {
+    uint32_t ne = S.d.n_emitters;
+    memset((void *) ds, 0, sizeof(*ds)); ds->emitter = -1;
+    if (ne == 0) return V3(0.f);
+    uint32_t index = 0; float emitter_weight = 1.f, pmf = 1.f;
+    if (ne > 1) {                                 /* scene.cpp:265-288 */
+        float scaled = sx * (float) ne;
+        index = std::min((uint32_t) scaled, ne - 1u);
+        emitter_weight = (float) ne; sx = scaled - (float) index; pmf = 1.f / (float) ne;
+    }
+    const lrt_emitter_desc &E = S.emitters[index];
+    ds->emitter = (int) index; ds->delta = false;
+    V3 spec(0.f);
+    if (E.type == LRT_EMITTER_AREA) {
+        /* src/shapes/rectangle.cpp:181-199 + src/render/shape.cpp:343-361 + src/emitters/area.cpp sample_direction */
+        const lrt_shape_desc &sd = S.shapes[E.shape];
+        M4 tw; memcpy(tw.m, sd.to_world, sizeof(tw.m));
+        ds->p = xform_point(tw, V3(fmaf(sx, 2.f, -1.f), fmaf(sy, 2.f, -1.f), 0.f));
+        ds->n = S.area[index].n; if (sd.flip_normals) ds->n = -ds->n;
+        ds->pdf = S.area[index].inv_area;
+        ds->d = ds->p - ref_p;
+        float dist2 = squared_norm(ds->d);
+        ds->dist = sqrtf(dist2);
+        ds->d = ds->d / ds->dist;
+        float dp = fabsf(dot(ds->d, ds->n)), x = dist2 / dp;
+        ds->pdf *= std::isfinite(x) ? x : 0.f;
+        bool active = dot(ds->d, ds->n) < 0.f && ds->pdf != 0.f;
+        V3 rad(E.radiance[0], E.radiance[1], E.radiance[2]);
+        spec = active ? rad / ds->pdf : V3(0.f);
+    } else if (E.type == LRT_EMITTER_ENVMAP) {
+        /* src/emitters/envmap.cpp:415-459 */
+        float u, v, pdf; S.env_warp.sample(sx, sy, &u, &v, &pdf);
+        u += .5f / (float) (S.env_w - 1u);
+        bool active = pdf > 0.f;
+        float theta = v * kPi, phi = u * kTwoPi;
+        float st, ct, sp, cp; m_sincos(theta, &st, &ct); m_sincos(phi, &sp, &cp);
+        V3 d(cp * st, sp * st, ct);                /* dr::sphdir */
+        d = V3(d.y, d.z, -d.x);
+        float radius = fmaxf(S.bsphere_r, norm(ref_p - S.bsphere_c)), dist = 2.f * radius;
+        float inv_sin_theta = safe_rsqrt(fmaxf(sqr(d.x) + sqr(d.z), sqr(kEpsilon)));
+        d = xform_vec(S.env_to_world, d);
+        ds->p = ref_p + d * dist; ds->n = -d;
+        ds->pdf = active ? pdf * inv_sin_theta * (1.f / (2.f * sqr(kPi))) : 0.f;
+        ds->d = d; ds->dist = dist;
+        V3 val = env_eval_uv(S, u, v);
+        spec = active ? val / ds->pdf : V3(0.f);
+    } else {
+        /* src/emitters/constant.cpp sample_direction */
+        V3 d = square_to_uniform_sphere(sx, sy);
+        float radius = fmaxf(S.bsphere_r, norm(ref_p - S.bsphere_c)), dist = 2.f * radius;
+        ds->p = fma3(d, dist, ref_p); ds->n = -d; ds->pdf = kInvFourPi; ds->d = d; ds->dist = dist;
+        spec = V3(E.radiance[0], E.radiance[1], E.radiance[2]) / ds->pdf;
+    }
+    ds->pdf *= pmf;
+    spec = spec * emitter_weight;
+    return spec;
+}
+
+/* DirectionSample(scene, si, ref) (include/mitsuba/render/records.h:173-180) +
+   Scene::pdf_emitter_direction (src/render/scene.cpp:395-406) */
+static float pdf_emitter_direction(const Scene &S, V3 ref_p, const SI &si, int emitter) {
+    V3 rel = si.p - ref_p;
+    float dist = norm(rel);
+    V3 d = si.valid ? rel / dist : -si.wi;
+    float pmf = 1.f / (float) S.d.n_emitters;
+    const lrt_emitter_desc &E = S.emitters[emitter];
+    float value;
+    if (E.type == LRT_EMITTER_AREA) {             /* src/emitters/area.cpp pdf_direction + shape.cpp:363-374 */
+        float dp = dot(d, si.n);
+        if (!(dp < 0.f)) return 0.f;
+        float adp = fabsf(dp);
+        value = S.area[emitter].inv_area * (adp != 0.f ? (dist * dist) / adp : 0.f);
+    } else if (E.type == LRT_EMITTER_ENVMAP) {    /* src/emitters/envmap.cpp:461-475 */
+        V3 dl = xform_vec(S.env_to_local, d);
+        float u = m_atan2(dl.x, -dl.z) * kInvTwoPi, v = safe_acos(dl.y) * kInvPi;
+        u -= .5f / (float) (S.env_w - 1u);
+        u -= floorf(u); v -= floorf(v);
+        float inv_sin_theta = safe_rsqrt(fmaxf(sqr(dl.x) + sqr(dl.z), sqr(kEpsilon)));
+        value = S.env_warp.eval(u, v) * inv_sin_theta * (1.f / (2.f * sqr(kPi)));
+    } else value = kInvFourPi;
+    return value * pmf;
+}
+
+static inline int si_emitter(const Scene &S, const SI &si) { return si.valid ? S.shapes[si.shape].emitter : S.env; }
+static inline V3 emitter_eval(const Scene &S, int e, const SI &si) {
+    return si.valid ? emitter_eval_area(S, e, si) : emitter_eval_env(S, -si.wi);
+}
+
+static inline float mis_weight(float a, float b) { a *= a; b *= b; float w = a / (a + b); return std::isfinite(w) ? w : 0.f; }
+static inline float idx3(V3 v, uint32_t c) { return c == 0 ? v.x : (c == 1 ? v.y : v.z); }
+
+/* ---------------------------------------------------------------- media */
+struct MI { float t; V3 p, wi; V3 sigma_s, sigma_n, sigma_t, combined; float mint; int medium;
+            bool valid() const { return t != kInf; } };
+
+/* src/render/medium.cpp:40-82 + src/media/homogeneous.cpp:153-181 */
+static MI medium_sample_interaction(const Scene &S, int m, const Ray &ray, float sample, uint32_t channel) {
+    const lrt_medium_desc &M = S.media[m];
+    MI mei; mei.wi = -ray.d; mei.medium = m;
+    float mint = 0.f, maxt = fminf(ray.maxt, kInf);
+    V3 sigmat = V3(M.sigma_t[0], M.sigma_t[1], M.sigma_t[2]) * M.scale;
+    float mm = idx3(sigmat, channel);
+    float sampled_t = mint + (-m_log(1.f - sample) / mm);
+    bool valid = sampled_t <= maxt;
+    mei.t = valid ? sampled_t : kInf;
+    mei.p = fma3(ray.d, sampled_t, ray.o);
+    mei.mint = mint;
+    V3 albedo(M.albedo[0], M.albedo[1], M.albedo[2]);
+    mei.sigma_t = valid ? sigmat : V3(0.f);
+    mei.sigma_s = valid ? sigmat * albedo : V3(0.f);
+    mei.sigma_n = V3(0.f);
+    mei.combined = sigmat;
+    return mei;
+}
+
+/* src/phase/hg.cpp:64-99, src/phase/isotropic.cpp:39-58 */
+static float hg_eval(float g, float cos_theta) {
+    float temp = 1.f + sqr(g) + 2.f * g * cos_theta;
+    return kInvFourPi * (1.f - sqr(g)) / (temp * sqrtf(temp));
+}
+static void phase_sample(const lrt_medium_desc &M, V3 wi, float s2x, float s2y, V3 *wo, float *pdf) {
+    if (M.phase == LRT_PHASE_HG) {
+        float g = M.g;
+        float sqr_term = (1.f - sqr(g)) / (1.f - g + 2.f * g * s2x);
+        float cos_theta = (1.f + sqr(g) - sqr(sqr_term)) / (2.f * g);
+        if (fabsf(g) < kEpsilon) cos_theta = 1.f - 2.f * s2x;
+        float sin_theta = safe_sqrt(1.f - sqr(cos_theta));
+        float sp, cp; m_sincos(2.f * kPi * s2y, &sp, &cp);
+        Frame f(wi);
+        *wo = f.to_world(V3(sin_theta * cp, sin_theta * sp, -cos_theta));
+        *pdf = hg_eval(g, -cos_theta);
+    } else {
+        *wo = square_to_uniform_sphere(s2x, s2y);
+        *pdf = kInvFourPi;
+    }
+}
+static float phase_eval(const lrt_medium_desc &M, V3 wi, V3 wo) {
+    return M.phase == LRT_PHASE_HG ? hg_eval(M.g, dot(wo, wi)) : kInvFourPi;
+}
+
+/* ------------------------------------------------------------ integrators */
+struct Ctx {
+    const Scene &S; PCG32 rng; int max_depth, rr_depth; bool hide_emitters;
+    uint64_t n_iter = 0, n_shadow = 0, n_shadow_needed = 0;
+    Ctx(const Scene &s) : S(s) {}
+    float next() { return rng.next(); }
+};
+
+static inline int target_medium(const lrt_shape_desc &sd, V3 d, V3 n) {   /* interaction.h:330-344 */
+    return dot(d, n) > 0.f ? sd.exterior_medium : sd.interior_medium;
+}
+static inline bool is_medium_transition(const lrt_shape_desc &sd) { return sd.interior_medium >= 0 || sd.exterior_medium >= 0; }
+
+/* src/integrators/volpath.cpp:400-554.  ref_n is zero for medium interactions. */
+static V3 volpath_sample_emitter(Ctx &C, V3 ref_p, V3 ref_n, const SI *ref_si, int medium, uint32_t channel, DirSample *ds_out) {
+    const Scene &S = C.S;
+    V3 transmittance(1.f);
+    float sx = C.next(), sy = C.next();
+    DirSample ds; V3 emitter_val = sample_emitter_direction(S, ref_p, sx, sy, &ds);
+    *ds_out = ds;
+    if (ds.pdf == 0.f) return V3(0.f);
+    Ray ray = spawn_ray_to(ref_p, ref_n, ds.p);
+    float max_dist = ray.maxt;
+    if (ref_si && is_medium_transition(S.shapes[ref_si->shape]))
+        medium = target_medium(S.shapes[ref_si->shape], ray.d, ref_si->n);
+    float total_dist = 0.f;
+    SI si; memset((void *) &si, 0, sizeof(si));
+    bool needs_intersection = true, active = true;
+    while (active) {
+        float remaining_dist = max_dist - total_dist;
+        ray.maxt = remaining_dist;
+        if (!(remaining_dist > 0.f)) break;
+        bool escaped_medium = false, active_medium = medium >= 0, active_surface = !active_medium;
+        if (active_medium) {
+            const lrt_medium_desc &M = S.media[medium];
+            MI mei = medium_sample_interaction(S, medium, ray, C.next(), channel);
+            if (mei.valid()) ray.maxt = fminf(mei.t, remaining_dist);
+            bool elide = false;
+            if (needs_intersection) {
+                /* the query cannot change the result when the sampled collision is real
+                   (sigma_n = 0) and every surface blocks (no null BSDF): both outcomes give 0 */
+                elide = mei.valid() && !S.has_null_bsdf;
+                C.n_shadow++; if (!elide) C.n_shadow_needed++;
+                Hit h = S.intersect(ray, false, false);
+                si = S.compute_si(ray, h);
+            }
+            if (si.t < mei.t) mei.t = kInf;
+            needs_intersection = false;
+            bool spectral = M.has_spectral_extinction;
+            if (spectral) {
+                float t = fminf(remaining_dist, fminf(mei.t, si.t)) - mei.mint;
+                V3 tr(m_exp(-t * mei.combined.x), m_exp(-t * mei.combined.y), m_exp(-t * mei.combined.z));
+                V3 ffp = (si.t < mei.t || mei.t > remaining_dist) ? tr : tr * mei.combined;
+                float tr_pdf = idx3(ffp, channel);
+                transmittance *= (tr_pdf > 0.f) ? tr / tr_pdf : V3(0.f);
+            }
+            if ((mei.t > remaining_dist) && mei.valid()) total_dist = ds.dist;
+            if (mei.t > remaining_dist) mei.t = kInf;
+            escaped_medium = !mei.valid();
+            active_medium = mei.valid();
+            if (active_medium) {
+                total_dist += mei.t;
+                ray.o = mei.p;
+                si.t = si.t - mei.t;
+                if (spectral) transmittance *= mei.sigma_n;
+                else transmittance *= mei.sigma_n / mei.combined;
+            }
+        }
+        bool intersect = active_surface && needs_intersection;
+        if (intersect) {
+            C.n_shadow++; C.n_shadow_needed++;
+            Hit h = S.intersect(ray, false, false);
+            si = S.compute_si(ray, h);
+            needs_intersection = false;
+        }
+        active_surface = active_surface || escaped_medium;
+        if (active_surface) total_dist += si.t;
+        active_surface = active_surface && si.valid && !active_medium;
+        if (active_surface) {
+            int b = S.shapes[si.shape].bsdf;
+            transmittance *= bsdf_null_transmission(S, b);
+            Ray nr = spawn_ray(si.p, si.n, ray.d);
+            ray = nr;
+        }
+        ray.maxt = remaining_dist;
+        needs_intersection = needs_intersection || active_surface;
+        active = (active_medium || active_surface) && any_nonzero(transmittance);
+        if (active_surface && is_medium_transition(S.shapes[si.shape]))
+            medium = target_medium(S.shapes[si.shape], ray.d, si.n);
+    }
+    return transmittance * emitter_val;
+}
+
+/* src/integrators/volpath.cpp:93-396 */
+static void volpath_sample(Ctx &C, Ray ray, int medium, V3 *out, bool *out_valid) {
+    const Scene &S = C.S;
+    bool valid_ray = !C.hide_emitters && S.env >= 0;
+    float eta = 1.f;
+    V3 throughput(1.f), result(0.f);
+    bool specular_chain = !C.hide_emitters;
+    uint32_t depth = 0;
+    uint32_t channel = std::min((uint32_t) (C.next() * 3.f), 2u);
+    SI si; memset((void *) &si, 0, sizeof(si));
+    bool needs_intersection = true, active = true;
+    V3 last_scatter_p(0.f);
+    float last_scatter_direction_pdf = 1.f;
+    const uint32_t max_depth = (uint32_t) C.max_depth;
+    while (active) {
+        C.n_iter++;
+        active = any_nonzero(throughput);
+        float q = fminf(max3(throughput) * sqr(eta), .95f);
+        bool perform_rr = depth > (uint32_t) C.rr_depth;
+        if (active) { float u = C.next(); active = (u < q) || !perform_rr; }
+        if (perform_rr) throughput *= rcp(q);
+        active = active && depth < max_depth;
+        if (!active) break;
+
+        bool active_medium = medium >= 0, active_surface = !active_medium;
+        bool act_medium_scatter = false, escaped_medium = false;
+        MI mei; mei.t = kInf;
+        if (active_medium) {
+            const lrt_medium_desc &M = S.media[medium];
+            mei = medium_sample_interaction(S, medium, ray, C.next(), channel);
+            if (mei.valid()) ray.maxt = mei.t;
+            if (needs_intersection) { Hit h = S.intersect(ray, false, false); si = S.compute_si(ray, h); }
+            needs_intersection = false;
+            if (si.t < mei.t) mei.t = kInf;
+            if (M.has_spectral_extinction) {      /* medium.cpp:92-104 */
+                float t = fminf(mei.t, si.t) - mei.mint;
+                V3 tr(m_exp(-t * mei.combined.x), m_exp(-t * mei.combined.y), m_exp(-t * mei.combined.z));
+                V3 pdf = (si.t < mei.t) ? tr : tr * mei.combined;
+                float tr_pdf = idx3(pdf, channel);
+                throughput *= (tr_pdf > 0.f) ? tr / tr_pdf : V3(0.f);
+            }
+            escaped_medium = !mei.valid();
+            active_medium = mei.valid();
+            if (active_medium) {
+                float null_scatter_prob = mean3(mei.sigma_n / mei.combined);
+                bool null_scatter = C.next() < null_scatter_prob;
+                /* homogeneous media: sigma_n = 0, the null branch (volpath.cpp:243-259) is unreachable */
+                (void) null_scatter;
+                act_medium_scatter = true;
+                depth += 1;
+                last_scatter_p = mei.p;
+            }
+        }
+        active = active && depth < max_depth;
+        act_medium_scatter = act_medium_scatter && active;
+        if (act_medium_scatter) {
+            const lrt_medium_desc &M = S.media[medium];
+            if (M.has_spectral_extinction) throughput *= mei.sigma_s / mean3(mei.sigma_t / mei.combined);
+            else throughput *= mei.sigma_s / mei.sigma_t;
+            bool sample_emitters = M.sample_emitters;
+            valid_ray = true;
+            specular_chain = !sample_emitters;
+            if (sample_emitters) {
+                DirSample ds;
+                V3 emitted = volpath_sample_emitter(C, mei.p, V3(0.f), nullptr, medium, channel, &ds);
+                float phase_val = phase_eval(M, mei.wi, ds.d);
+                result += throughput * phase_val * emitted * mis_weight(ds.pdf, ds.delta ? 0.f : phase_val);
+            }
+            float s1 = C.next(); (void) s1;
+            float s2x = C.next(), s2y = C.next();
+            V3 wo; float phase_pdf; phase_sample(M, mei.wi, s2x, s2y, &wo, &phase_pdf);
+            act_medium_scatter = phase_pdf > 0.f;
+            if (act_medium_scatter) {
+                ray = spawn_ray(mei.p, V3(0.f), wo);
+                needs_intersection = true;
+                last_scatter_direction_pdf = phase_pdf;
+                /* throughput *= phase_weight (= 1) */
+            }
+        }
+        /* --------------------- surface interactions --------------------- */
+        active_surface = active_surface || escaped_medium;
+        bool intersect = active_surface && needs_intersection;
+        if (intersect) { Hit h = S.intersect(ray, false, false); si = S.compute_si(ray, h); }
+        if (active_surface) {
+            if (C.hide_emitters && depth == 0 && intersect) {      /* volpath.cpp:304-320, integrator.cpp:96-123 */
+                bool skip = si.valid && S.shapes[si.shape].emitter >= 0;
+                if (skip) {
+                    Ray r2 = spawn_ray(si.p, si.n, ray.d);
+                    bool a = true; Hit h; h.prim = 0xffffffffu; h.t = kInf;
+                    while (a) {
+                        h = S.intersect(r2, false, false);
+                        a = h.valid() && S.shapes[S.face_shape[h.prim]].emitter >= 0;
+                        if (a) { SI s2 = S.compute_si(r2, h); r2 = spawn_ray(s2.p, s2.n, r2.d); }
+                    }
+                    si = S.compute_si(r2, h);
+                }
+            }
+            bool ray_from_camera = depth == 0;
+            bool count_direct = ray_from_camera || specular_chain;
+            int emitter = si_emitter(S, si);
+            bool active_e = emitter >= 0 && !(depth == 0 && C.hide_emitters);
+            if (active_e) {
+                float emitter_pdf = 1.f;
+                if (!count_direct) emitter_pdf = pdf_emitter_direction(S, last_scatter_p, si, emitter);
+                V3 emitted = emitter_eval(S, emitter, si);
+                V3 contrib = count_direct ? throughput * emitted
+                                          : throughput * mis_weight(last_scatter_direction_pdf, emitter_pdf) * emitted;
+                result += contrib;
+            }
+        }
+        active_surface = active_surface && si.valid;
+        if (active_surface) {
+            const lrt_shape_desc &sd = S.shapes[si.shape];
+            int b = sd.bsdf;
+            int flags = bsdf_flags(S, b);
+            bool active_e = (flags & F_SMOOTH) && (depth + 1 < max_depth);
+            if (active_e) {
+                DirSample ds;
+                V3 emitted = volpath_sample_emitter(C, si.p, si.n, &si, medium, channel, &ds);
+                V3 wo = si.sh.to_local(ds.d);
+                V3 bsdf_val = bsdf_eval(S, b, si, wo);
+                float bpdf = bsdf_pdf(S, b, si, wo);
+                result += throughput * bsdf_val * mis_weight(ds.pdf, ds.delta ? 0.f : bpdf) * emitted;
+            }
+            float s1 = C.next(), s2x = C.next(), s2y = C.next();
+            BSDFSample bs; V3 bsdf_val;
+            bsdf_sample(S, b, si, s1, s2x, s2y, &bs, &bsdf_val);
+            throughput *= bsdf_val;
+            eta *= bs.eta;
+            ray = spawn_ray(si.p, si.n, si.sh.to_world(bs.wo));
+            needs_intersection = true;
+            bool non_null = !(bs.type & F_NULL);
+            if (non_null) { depth += 1; last_scatter_p = si.p; last_scatter_direction_pdf = bs.pdf; valid_ray = true; }
+            specular_chain = specular_chain || (non_null && (bs.type & F_DELTA));
+            specular_chain = specular_chain && !(bs.type & F_SMOOTH);
+            if (is_medium_transition(sd)) medium = target_medium(sd, ray.d, si.n);
+        }
+        active = active && (active_surface || active_medium);
+    }
+    *out = result; *out_valid = valid_ray;
+}
+
+/* src/integrators/path.cpp:95-351 */
+static void path_sample(Ctx &C, Ray ray, V3 *out, bool *out_valid) {
+    const Scene &S = C.S;
+    *out = V3(0.f); *out_valid = false;
+    if (C.max_depth == 0) return;
+    V3 throughput(1.f), result(0.f);
+    float eta = 1.f; uint32_t depth = 0;
+    bool valid_ray = !C.hide_emitters && S.env >= 0;
+    V3 prev_p(0.f); float prev_bsdf_pdf = 1.f; bool prev_bsdf_delta = true;
+    const uint32_t max_depth = (uint32_t) C.max_depth;
+    Hit pi = S.intersect(ray, false, false);
+    if (C.hide_emitters) {                        /* path.cpp:178-192 */
+        bool skip = pi.valid() && S.shapes[S.face_shape[pi.prim]].emitter >= 0;
+        if (skip) {
+            SI s0 = S.compute_si(ray, pi);
+            Ray r2 = spawn_ray(s0.p, s0.n, ray.d);
+            bool a = true; Hit h; h.prim = 0xffffffffu; h.t = kInf;
+            while (a) {
+                h = S.intersect(r2, false, false);
+                a = h.valid() && S.shapes[S.face_shape[h.prim]].emitter >= 0;
+                if (a) { SI s2 = S.compute_si(r2, h); r2 = spawn_ray(s2.p, s2.n, r2.d); }
+            }
+            pi = h; ray = r2;   /* NB: reference keeps ls.ray; si is recomputed from pi with ls.ray */
+        }
+    }
+    bool active = true;
+    while (active) {
+        C.n_iter++;
+        SI si = S.compute_si(ray, pi);
+        int emitter = si_emitter(S, si);
+        if (emitter >= 0) {
+            float em_pdf = 0.f;
+            if (!prev_bsdf_delta) em_pdf = pdf_emitter_direction(S, prev_p, si, emitter);
+            float mis_bsdf = mis_weight(prev_bsdf_pdf, em_pdf);
+            V3 em = (prev_bsdf_pdf > 0.f) ? emitter_eval(S, emitter, si) : V3(0.f);
+            em = em * mis_bsdf;
+            result = V3(fmaf(throughput.x, em.x, result.x), fmaf(throughput.y, em.y, result.y), fmaf(throughput.z, em.z, result.z));
+        }
+        bool active_next = (depth + 1 < max_depth) && si.valid;
+        if (!active_next) { valid_ray = valid_ray || (emitter >= 0 && !C.hide_emitters); break; }
+        const lrt_shape_desc &sd = S.shapes[si.shape];
+        int b = sd.bsdf;
+        bool active_em = (bsdf_flags(S, b) & F_SMOOTH) != 0;
+        DirSample ds; memset((void *) &ds, 0, sizeof(ds));
+        V3 em_weight(0.f), wo(0.f);
+        if (active_em) {
+            float sx = C.next(), sy = C.next();
+            em_weight = sample_emitter_direction(S, si.p, sx, sy, &ds);
+            if (ds.pdf != 0.f) {                  /* scene.cpp:361-365: test_visibility */
+                Ray sr = spawn_ray_to(si.p, si.n, ds.p);
+                C.n_shadow++; C.n_shadow_needed++;
+                Hit h = S.intersect(sr, true, false);
+                if (h.valid()) { em_weight = V3(0.f); ds.pdf = 0.f; }
+            }
+            active_em = ds.pdf != 0.f;
+            wo = si.sh.to_local(ds.d);
+        }
+        float s1 = C.next(), s2x = C.next(), s2y = C.next();
+        V3 bsdf_val = bsdf_eval(S, b, si, wo);
+        float bpdf = bsdf_pdf(S, b, si, wo);
+        BSDFSample bs; V3 bsdf_weight;
+        bsdf_sample(S, b, si, s1, s2x, s2y, &bs, &bsdf_weight);
+        if (active_em) {
+            float mis_em = ds.delta ? 1.f : mis_weight(ds.pdf, bpdf);
+            V3 c = bsdf_val * em_weight * mis_em;
+            result = V3(fmaf(throughput.x, c.x, result.x), fmaf(throughput.y, c.y, result.y), fmaf(throughput.z, c.z, result.z));
+        }
+        ray = spawn_ray(si.p, si.n, si.sh.to_world(bs.wo));
+        throughput *= bsdf_weight;
+        eta *= bs.eta;
+        valid_ray = valid_ray || !(bs.type & F_NULL);
+        prev_p = si.p; prev_bsdf_pdf = bs.pdf; prev_bsdf_delta = (bs.type & F_DELTA) != 0;
+        depth += 1;
+        float tmax = max3(throughput);
+        float rr_prob = fminf(tmax * sqr(eta), .95f);
+        bool rr_active = depth >= (uint32_t) C.rr_depth, rr_continue = C.next() < rr_prob;
+        if (rr_active) throughput *= rcp(rr_prob);
+        active = active_next && (!rr_active || rr_continue) && (tmax != 0.f);
+        if (active) pi = S.intersect(ray, false, false);
+    }
+    *out = valid_ray ? result : V3(0.f); *out_valid = valid_ray;
+}
+
+/* ------------------------------------------------------------------ film */
+struct Opts { int integrator, max_depth, rr_depth; bool hide_emitters; uint32_t spp, seed; };
+
+static Opts resolve_opts(const Scene &S, const lrt_render_opts *o) {
+    Opts r;
+    r.integrator = (o && o->integrator >= 0) ? o->integrator : S.d.integrator.type;
+    r.max_depth = (o && o->max_depth != -2) ? o->max_depth : S.d.integrator.max_depth;
+    r.rr_depth = (o && o->rr_depth >= 0) ? o->rr_depth : S.d.integrator.rr_depth;
+    r.hide_emitters = (o && o->hide_emitters >= 0) ? (o->hide_emitters != 0) : (S.d.integrator.hide_emitters != 0);
+    r.spp = (o && o->spp) ? o->spp : S.d.sample_count;
+    r.seed = o ? o->seed : 0;
+    return r;
+}
+
+struct SampleOut { float r, g, b, a; float px, py; };
+
+/* src/render/integrator.cpp:321-338 (lane -> pixel) + :449-521 (render_sample) */
+static SampleOut render_lane(const Scene &S, const Opts &O, uint64_t lane, orc_stats *st) {
+    const lrt_film_desc &F = S.d.film;
+    Ctx C(S); C.max_depth = O.max_depth; C.rr_depth = O.rr_depth; C.hide_emitters = O.hide_emitters;
+    C.rng = lane_rng(S.d.sampler_seed, O.seed, (uint32_t) lane);
+    uint32_t idx = (uint32_t) (lane / O.spp);
+    uint32_t W = (uint32_t) F.crop_width;
+    uint32_t py = idx / W, px = idx - py * W;
+    float posx = (float) ((int) px + F.crop_offset_x), posy = (float) ((int) py + F.crop_offset_y);
+    float sclx = 1.f / (float) F.crop_width, scly = 1.f / (float) F.crop_height;
+    float offx = -(float) F.crop_offset_x * sclx, offy = -(float) F.crop_offset_y * scly;
+    float jx = C.next(), jy = C.next();
+    float spx = posx + jx, spy = posy + jy;
+    float ax = fmaf(spx, sclx, offx), ay = fmaf(spy, scly, offy);
+    Ray ray = sample_ray(S, ax, ay);
+    V3 L; bool valid;
+    if (O.integrator == LRT_INTEGRATOR_PATH) path_sample(C, ray, &L, &valid);
+    else volpath_sample(C, ray, S.d.sensor.medium, &L, &valid);
+    if (st) { st->n_iter += C.n_iter; st->n_shadow += C.n_shadow; st->n_shadow_needed += C.n_shadow_needed; st->n_samples += 1; }
+    SampleOut o; o.r = L.x; o.g = L.y; o.b = L.z; o.a = valid ? 1.f : 0.f;
+    bool box = F.rfilter == LRT_RFILTER_BOX;
+    o.px = box ? posx : spx; o.py = box ? posy : spy;
+    return o;
+}
+
+/* src/render/imageblock.cpp:174-232 (box) and :431-500 (coalesced footprint) */
+static void film_put(const Scene &S, float *film, const SampleOut &s) {
+    const lrt_film_desc &F = S.d.film;
+    int C = F.has_alpha ? 5 : 4, W = F.crop_width, H = F.crop_height;
+    float vals[5]; int k = 0;
+    vals[k++] = s.r; vals[k++] = s.g; vals[k++] = s.b; if (F.has_alpha) vals[k++] = s.a; vals[k++] = 1.f;
+    if (F.rfilter == LRT_RFILTER_BOX) {
+        int x = (int) floorf(s.px) - F.crop_offset_x, y = (int) floorf(s.py) - F.crop_offset_y;
+        if (x < 0 || y < 0 || x >= W || y >= H) return;
+        float *p = film + ((size_t) y * W + x) * C;
+        for (int c = 0; c < C; ++c) p[c] += vals[c];
+        return;
+    }
+    int n = (int) ceilf(S.rf_radius - .5f), count = 2 * n + 1;
+    int pix = (int) floorf(s.px) - n, piy = (int) floorf(s.py) - n;
+    float relx = (float) pix + .5f - s.px, rely = (float) piy + .5f - s.py;
+    float wx[16], wy[16];
+    for (int i = 0; i < count; ++i) { wx[i] = S.rfilter_eval(relx); wy[i] = S.rfilter_eval(rely); relx += 1.f; rely += 1.f; }
+    for (int ys = 0; ys < count; ++ys) {
+        int y = piy - F.crop_offset_y + ys;
+        if (y < 0 || y >= H) continue;
+        for (int xs = 0; xs < count; ++xs) {
+            int x = pix - F.crop_offset_x + xs;
+            if (x < 0 || x >= W) continue;
+            float w = wy[ys] * wx[xs];
+            float *p = film + ((size_t) y * W + x) * C;
+            for (int c = 0; c < C; ++c) p[c] += vals[c] * w;
+        }
+    }
+}
+
+/* src/films/hdrfilm.cpp:306-410 develop (RGB[A] / W, W == 0 -> 1) */
+static void film_develop(const Scene &S, const float *film, float *image) {
+    const lrt_film_desc &F = S.d.film;
+    int C = F.has_alpha ? 5 : 4, T = F.has_alpha ? 4 : 3;
+    size_t np = (size_t) F.crop_width * F.crop_height;
+    for (size_t i = 0; i < np; ++i) {
+        float w = film[i * C + C - 1]; if (w == 0.f) w = 1.f;
+        for (int c = 0; c < T; ++c) image[i * T + c] = film[i * C + c] / w;
+    }
+}
+
+static int hw_threads(int n) { if (n > 0) return n; unsigned h = std::thread::hardware_concurrency(); return h ? (int) h : 1; }
+
+template <typename Fn> static void parallel_for(uint64_t n, int n_threads, Fn fn) {
+    n_threads = hw_threads(n_threads);
+    if (n_threads == 1 || n < 256) { fn(0, n, 0); return; }
+    std::vector<std::thread> th;
+    std::atomic<uint64_t> next(0);
+    const uint64_t grain = std::max<uint64_t>(64, std::min<uint64_t>(16384, n / (uint64_t) (n_threads * 8) + 1));
+    for (int t = 0; t < n_threads; ++t)
+        th.emplace_back([&, t]() {
+            for (;;) { uint64_t b = next.fetch_add(grain); if (b >= n) break; fn(b, std::min(n, b + grain), t); }
+        });
+    for (auto &x : th) x.join();
+}
+
+} // namespace orc
+
+using namespace orc;
+
+static thread_local std::string g_err;
+extern "C" const char *orc_last_error(void) { return g_err.c_str(); }
+
+extern "C" int orc_render_samples(orc_scene *s, const lrt_render_opts *opts, uint64_t lane_begin, uint32_t n,
+                                  int n_threads, float *out, orc_stats *stats) {
+    const Scene &S = s->s; Opts O = resolve_opts(S, opts);
+    int nt = hw_threads(n_threads);
+    std::vector<orc_stats> st(nt); for (auto &x : st) memset(&x, 0, sizeof(x));
+    parallel_for(n, nt, [&](uint64_t b, uint64_t e, int t) {
+        for (uint64_t i = b; i < e; ++i) {
+            SampleOut o = render_lane(S, O, lane_begin + i, &st[t]);
+            out[4 * i] = o.r; out[4 * i + 1] = o.g; out[4 * i + 2] = o.b; out[4 * i + 3] = o.a;
+        }
+    });
+    if (stats) { memset(stats, 0, sizeof(*stats)); for (auto &x : st) { stats->n_iter += x.n_iter; stats->n_shadow += x.n_shadow; stats->n_shadow_needed += x.n_shadow_needed; stats->n_samples += x.n_samples; } }
+    return 0;
+}
+
+extern "C" int orc_render(orc_scene *s, const lrt_render_opts *opts, int n_threads, float *film_raw, float *image, orc_stats *stats) {
+    const Scene &S = s->s; Opts O = resolve_opts(S, opts);
+    const lrt_film_desc &F = S.d.film;
+    int C = F.has_alpha ? 5 : 4;
+    size_t np = (size_t) F.crop_width * F.crop_height;
+    uint64_t N = (uint64_t) np * O.spp;
+    if (N > 0xffffffffull) { g_err = "orc_render: more than 2^32 lanes"; return 1; }
+    std::vector<float> film(np * C, 0.f);
+    int nt = hw_threads(n_threads);
+    std::vector<orc_stats> st(nt); for (auto &x : st) memset(&x, 0, sizeof(x));
+    const uint64_t chunk = 1u << 20;
+    std::vector<SampleOut> buf((size_t) std::min<uint64_t>(chunk, N));
+    for (uint64_t base = 0; base < N; base += chunk) {
+        uint64_t cnt = std::min<uint64_t>(chunk, N - base);
+        parallel_for(cnt, nt, [&](uint64_t b, uint64_t e, int t) {
+            for (uint64_t i = b; i < e; ++i) buf[i] = render_lane(S, O, base + i, &st[t]);
+        });
+        for (uint64_t i = 0; i < cnt; ++i) film_put(S, film.data(), buf[i]);   /* lane order: deterministic */
+    }
+    if (film_raw) memcpy(film_raw, film.data(), film.size() * sizeof(float));
+    if (image) film_develop(S, film.data(), image);
+    if (stats) { memset(stats, 0, sizeof(*stats)); for (auto &x : st) { stats->n_iter += x.n_iter; stats->n_shadow += x.n_shadow; stats->n_shadow_needed += x.n_shadow_needed; stats->n_samples += x.n_samples; } }
+    return 0;
+}
+
+/* src/render/integrator.cpp:190-273,399-434: scalar-variant tiling (CPU baseline workload) */
+extern "C" int orc_render_scalar(orc_scene *s, const lrt_render_opts *opts, int n_threads, float *film_raw, float *image, orc_stats *stats) {
+    const Scene &S = s->s; Opts O = resolve_opts(S, opts);
+    const lrt_film_desc &F = S.d.film;
+    int C = F.has_alpha ? 5 : 4, W = F.crop_width, H = F.crop_height;
+    size_t np = (size_t) W * H;
+    std::vector<float> film(np * C, 0.f);
+    const int bs = 32;
+    int bx = (W + bs - 1) / bs, by = (H + bs - 1) / bs;
+    int nt = hw_threads(n_threads);
+    std::vector<orc_stats> st(nt); for (auto &x : st) memset(&x, 0, sizeof(x));
+    std::mutex mtx;
+    parallel_for((uint64_t) bx * by, nt, [&](uint64_t b0, uint64_t b1, int t) {
+        for (uint64_t blk = b0; blk < b1; ++blk) {
+            int ox = (int) (blk % bx) * bs, oy = (int) (blk / bx) * bs;
+            int w = std::min(bs, W - ox), h = std::min(bs, H - oy);
+            std::vector<SampleOut> local; local.reserve((size_t) w * h * O.spp);
+            for (int i = 0; i < bs * bs; ++i) {
+                /* dr::morton_decode<Point2u>(i) */
+                auto compact = [](uint32_t x) { x &= 0x55555555u; x = (x ^ (x >> 1)) & 0x33333333u; x = (x ^ (x >> 2)) & 0x0f0f0f0fu;
+                                                x = (x ^ (x >> 4)) & 0x00ff00ffu; x = (x ^ (x >> 8)) & 0x0000ffffu; return x; };
+                int lx = (int) compact((uint32_t) i), ly = (int) compact((uint32_t) i >> 1);
+                if (lx >= w || ly >= h) continue;
+                Ctx Cx(S); Cx.max_depth = O.max_depth; Cx.rr_depth = O.rr_depth; Cx.hide_emitters = O.hide_emitters;
+                uint32_t sd = O.seed * (uint32_t) (W * H) + (uint32_t) blk * (uint32_t) (bs * bs) + (uint32_t) i;
+                Cx.rng.seed((uint64_t) (S.d.sampler_seed + sd), 0xda3e39cb94b95bdbULL);
+                float posx = (float) (ox + lx + F.crop_offset_x), posy = (float) (oy + ly + F.crop_offset_y);
+                for (uint32_t k = 0; k < O.spp; ++k) {
+                    float jx = Cx.next(), jy = Cx.next();
+                    float spx = posx + jx, spy = posy + jy;
+                    Ray ray = sample_ray(S, fmaf(spx, 1.f / (float) W, -(float) F.crop_offset_x / (float) W),
+                                         fmaf(spy, 1.f / (float) H, -(float) F.crop_offset_y / (float) H));
+                    V3 L; bool valid;
+                    if (O.integrator == LRT_INTEGRATOR_PATH) path_sample(Cx, ray, &L, &valid);
+                    else volpath_sample(Cx, ray, S.d.sensor.medium, &L, &valid);
+                    bool box = F.rfilter == LRT_RFILTER_BOX;
+                    local.push_back({ L.x, L.y, L.z, valid ? 1.f : 0.f, box ? posx : spx, box ? posy : spy });
+                }
+                st[t].n_iter += Cx.n_iter; st[t].n_shadow += Cx.n_shadow; st[t].n_shadow_needed += Cx.n_shadow_needed; st[t].n_samples += O.spp;
+            }
+            std::lock_guard<std::mutex> lk(mtx);
+            for (auto &so : local) film_put(S, film.data(), so);
+        }
+    });
+    if (film_raw) memcpy(film_raw, film.data(), film.size() * sizeof(float));
+    if (image) film_develop(S, film.data(), image);
+    if (stats) { memset(stats, 0, sizeof(*stats)); for (auto &x : st) { stats->n_iter += x.n_iter; stats->n_shadow += x.n_shadow; stats->n_shadow_needed += x.n_shadow_needed; stats->n_samples += x.n_samples; } }
+    return 0;
+}
+
+extern "C" int orc_trace(orc_scene *s, const lrt_rays_soa *rays, const lrt_hits_soa *hits, uint32_t n, int any_hit, int brute) {
+    const Scene &S = s->s;
+    parallel_for(n, 0, [&](uint64_t b, uint64_t e, int) {
+        for (uint64_t i = b; i < e; ++i) {
+            Ray r; r.o = V3(rays->ox[i], rays->oy[i], rays->oz[i]); r.d = V3(rays->dx[i], rays->dy[i], rays->dz[i]); r.maxt = rays->tmax[i];
+            Hit h = S.intersect(r, any_hit != 0, brute != 0);
+            if (any_hit) { hits->t[i] = h.valid() ? 0.f : kInf; continue; }
+            hits->t[i] = h.t; if (hits->u) hits->u[i] = h.u; if (hits->v) hits->v[i] = h.v; if (hits->prim) hits->prim[i] = h.prim;
+        }
+    });
+    return 0;
+}
+
+/* ---------------------------------------------------------- unit hooks */
+extern "C" void orc_tea32(uint32_t v0, uint32_t v1, int rounds, uint32_t *o0, uint32_t *o1) { tea32(v0, v1, rounds, o0, o1); }
+extern "C" float orc_tea_float32(uint32_t v0, uint32_t v1, int rounds) {   /* random.h:134-139 */
+    uint32_t a, b; tea32(v0, v1, rounds, &a, &b); return u2f((b >> 9) | 0x3f800000u) - 1.f;
+}
+extern "C" double orc_tea_float64(uint32_t v0, uint32_t v1, int rounds) {  /* random.h sample_tea_64 + float64 */
+    uint32_t a, b; tea32(v0, v1, rounds, &a, &b);
+    uint64_t u = (uint64_t) a + ((uint64_t) b << 32);
+    uint64_t bits = (u >> 12) | 0x3ff0000000000000ull; double d; memcpy(&d, &bits, 8); return d - 1.0;
+}
+extern "C" void orc_pcg32_u32(uint64_t initstate, uint64_t initseq, uint32_t n, uint32_t *out) {
+    PCG32 r; r.seed(initstate, initseq); for (uint32_t i = 0; i < n; ++i) out[i] = r.next_u32();
+}
+extern "C" void orc_lane_stream(uint32_t base_seed, uint32_t seed, uint32_t lane, uint32_t n, float *out) {
+    PCG32 r = lane_rng(base_seed, seed, lane); for (uint32_t i = 0; i < n; ++i) out[i] = r.next();
+}
+extern "C" void orc_math_eval(int fn, const float *x, const float *y, uint32_t n, float *out, float *out2) {
+    for (uint32_t i = 0; i < n; ++i) switch (fn) {
+        case 0: out[i] = m_log(x[i]); break;
+        case 1: out[i] = m_exp(x[i]); break;
+        case 2: m_sincos(x[i], &out[i], &out2[i]); break;
+        case 3: out[i] = m_atan2(y[i], x[i]); break;
+        case 4: out[i] = m_acos(x[i]); break;
+    }
+}
+extern "C" void orc_hg_sample(float g, const float wi[3], float u1, float u2, float wo[3], float *pdf) {
+    lrt_medium_desc M; memset(&M, 0, sizeof(M)); M.phase = LRT_PHASE_HG; M.g = g;
+    V3 w; phase_sample(M, V3(wi[0], wi[1], wi[2]), u1, u2, &w, pdf); wo[0] = w.x; wo[1] = w.y; wo[2] = w.z;
+}
+extern "C" float orc_hg_eval(float g, float c) { return hg_eval(g, c); }
+extern "C" void orc_square_to_cosine_hemisphere(float u1, float u2, float o[3]) { V3 v = square_to_cosine_hemisphere(u1, u2); o[0] = v.x; o[1] = v.y; o[2] = v.z; }
+extern "C" void orc_square_to_uniform_sphere(float u1, float u2, float o[3]) { V3 v = square_to_uniform_sphere(u1, u2); o[0] = v.x; o[1] = v.y; o[2] = v.z; }
+extern "C" void orc_fresnel(float c, float eta, float out[4]) { fresnel(c, eta, &out[0], &out[1], &out[2], &out[3]); }
+extern "C" void orc_envmap_sample(orc_scene *s, float u1, float u2, float ref[3], float d[3], float *pdf, float rgb[3]) {
+    DirSample ds; V3 w = sample_emitter_direction(s->s, V3(ref[0], ref[1], ref[2]), u1, u2, &ds);
+    d[0] = ds.d.x; d[1] = ds.d.y; d[2] = ds.d.z; *pdf = ds.pdf; rgb[0] = w.x; rgb[1] = w.y; rgb[2] = w.z;
+}
+extern "C" float orc_envmap_pdf(orc_scene *s, const float d[3]) {
+    SI si; memset((void *) &si, 0, sizeof(si)); si.valid = false; si.wi = V3(-d[0], -d[1], -d[2]);
+    return pdf_emitter_direction(s->s, V3(0.f), si, s->s.env);
+}
+extern "C" void orc_envmap_eval(orc_scene *s, const float d[3], float rgb[3]) {
+    V3 v = emitter_eval_env(s->s, V3(d[0], d[1], d[2])); rgb[0] = v.x; rgb[1] = v.y; rgb[2] = v.z;
+}
+extern "C" float orc_rfilter_eval(orc_scene *s, float x) { return s->s.rfilter_eval(x); }
+extern "C" void orc_sample_ray(orc_scene *s, float px, float py, float o[3], float d[3], float *maxt) {
+    Ray r = sample_ray(s->s, px, py); o[0] = r.o.x; o[1] = r.o.y; o[2] = r.o.z; d[0] = r.d.x; d[1] = r.d.y; d[2] = r.d.z; *maxt = r.maxt;
+}
