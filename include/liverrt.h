@@ -235,6 +235,14 @@ LRT_API lrt_status lrt_trace(lrt_scene *scene, const lrt_rays_soa *rays,
 LRT_API lrt_status lrt_param_set(lrt_scene *scene, const char *key, const float *v, int n);
 LRT_API lrt_status lrt_param_get(const lrt_scene *scene, const char *key, float *v, int n);
 
+/* Image files around the path (mi.Bitmap(path) / Bitmap.write, src/core/bitmap.cpp): 8/16-bit PNG and
+ * scanline OpenEXR (NONE/ZIPS/ZIP/PIZ) readers, uncompressed float32 EXR writer.  *data is
+ * h * w * channels floats in R,G,B[,A] (or Y[,A]) order, PNG values in [0,1] as stored (no
+ * gamma conversion); release it with lrt_image_free.  */
+LRT_API lrt_status lrt_image_read(const char *path, int *width, int *height, int *channels, float **data);
+LRT_API void       lrt_image_free(float *data);
+LRT_API lrt_status lrt_image_write_exr(const char *path, int width, int height, int channels, const float *data);
+
 #ifdef __cplusplus
 }
 #endif

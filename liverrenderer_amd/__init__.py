@@ -378,3 +378,60 @@ def render(scene, spp=0, seed=0, integrator=None, **kw):
 
 def render_stats(scene):
     return scene.stats()
+
+
+def scene_from_buffers(positions, faces, normals=None, texcoords=None, reflectance=(0.5, 0.5, 0.5), film=(64, 64),
+                       sensor_to_world=None, fov=45.0, spp=4, integrator="path", max_depth=-1, constant_radiance=None):
+    """Build a one-mesh scene from raw buffers through `lrt_scene_from_desc` (the "from buffers" entry of the C ABI).
+    The mesh gets a diffuse BSDF; an optional constant environment emitter lights it."""
+    L = _lib.lib()
+    pos = np.ascontiguousarray(positions, dtype=np.float32).reshape(-1, 3)
+    fc = np.ascontiguousarray(faces, dtype=np.uint32).reshape(-1, 3)
+    nv, nf = pos.shape[0], fc.shape[0]
+    nrm = np.zeros((nv, 3), np.float32) if normals is None else np.ascontiguousarray(normals, dtype=np.float32).reshape(-1, 3)
+    uv = np.zeros((nv, 2), np.float32) if texcoords is None else np.ascontiguousarray(texcoords, dtype=np.float32).reshape(-1, 2)
+    fshape = np.zeros(nf, np.uint32)
+    FP, UP = C.POINTER(C.c_float), C.POINTER(C.c_uint32)
+    shape = _lib.ShapeDesc(kind=0, first_face=0, n_faces=nf, bsdf=0, emitter=-1, interior_medium=-1, exterior_medium=-1,
+                           has_normals=int(normals is not None), has_texcoords=int(texcoords is not None), flip_normals=0)
+    shape.to_world[:] = list(np.eye(4, dtype=np.float32).reshape(-1))
+    tex = _lib.TextureDesc(type=0, width=0, height=0, channels=0)
+    tex.color0[:] = list(reflectance); tex.color1[:] = list(reflectance); tex.to_uv[:] = [1, 0, 0, 0, 1, 0, 0, 0, 1]
+    bsdf = _lib.BsdfDesc(type=0, reflectance=0, eta=1.0, nested=-1, texture=-1, scale=1.0)
+    d = _lib.SceneDesc()
+    d.n_vertices, d.n_faces, d.n_shapes, d.n_bsdfs, d.n_textures, d.n_media = nv, nf, 1, 1, 1, 0
+    d.positions, d.normals, d.texcoords = pos.ctypes.data_as(FP), nrm.ctypes.data_as(FP), uv.ctypes.data_as(FP)
+    d.faces, d.face_shape = fc.ctypes.data_as(UP), fshape.ctypes.data_as(UP)
+    d.shapes, d.bsdfs, d.textures = C.pointer(shape), C.pointer(bsdf), C.pointer(tex)
+    em = _lib.EmitterDesc(type=2, shape=-1, scale=1.0)
+    if constant_radiance is not None:
+        em.radiance[:] = list(constant_radiance); em.to_world[:] = list(np.eye(4, dtype=np.float32).reshape(-1))
+        d.n_emitters, d.emitters = 1, C.pointer(em)
+    tw = ScalarTransform4f() if sensor_to_world is None else sensor_to_world
+    d.sensor.to_world[:] = [float(x) for x in np.asarray(tw.matrix, dtype=np.float32).reshape(-1)]
+    d.sensor.fov_x, d.sensor.near_clip, d.sensor.far_clip, d.sensor.medium = fov, 1e-2, 1e4, -1
+    d.film.width, d.film.height = film; d.film.crop_width, d.film.crop_height = film
+    d.film.has_alpha, d.film.rfilter, d.film.rfilter_param = 0, 0, 0.5
+    d.integrator.type, d.integrator.max_depth, d.integrator.rr_depth, d.integrator.hide_emitters = _lib.INTEGRATOR[integrator], max_depth, 5, 0
+    d.sample_count, d.sampler_seed = spp, 0
+    h = C.c_void_p()
+    _lib.check(L.lrt_scene_from_desc(C.byref(d), C.byref(h)))
+    return Scene(h.value)
+
+
+def read_image(path):
+    """mi.Bitmap(path) as a float32 array (h, w, channels); PNG values are in [0, 1] as stored."""
+    L = _lib.lib()
+    w, h, c = C.c_int(), C.c_int(), C.c_int(); data = C.POINTER(C.c_float)()
+    _lib.check(L.lrt_image_read(os.fspath(path).encode(), C.byref(w), C.byref(h), C.byref(c), C.byref(data)))
+    try:
+        return np.ctypeslib.as_array(data, (h.value, w.value, c.value)).copy()
+    finally:
+        L.lrt_image_free(data)
+
+
+def write_exr(path, image):
+    img = np.ascontiguousarray(image, dtype=np.float32)
+    if img.ndim == 2:
+        img = img[..., None]
+    _lib.check(_lib.lib().lrt_image_write_exr(os.fspath(path).encode(), img.shape[1], img.shape[0], img.shape[2], img.ctypes.data))

@@ -3,6 +3,7 @@
 // thread-local message for lrt_last_error().
 #include "host_scene.h"
 #include "device_scene.h"
+#include "image_io.h"
 #include <cstring>
 #include <cstdio>
 #include <fstream>
@@ -176,6 +177,29 @@ lrt_status lrt_param_get(const lrt_scene *scene, const char *key, float *v, int 
     else if (!strcmp(rest, "phase_function.g")) v[0] = M->g;
     else return fail(LRT_ERR_INVALID, std::string("unknown parameter \"") + key + "\"");
     return LRT_OK;
+}
+
+lrt_status lrt_image_read(const char *path, int *width, int *height, int *channels, float **data) {
+    if (!path || !width || !height || !channels || !data) return fail(LRT_ERR_INVALID, "lrt_image_read: null argument");
+    *data = nullptr;
+    LRT_TRY
+        Image im = read_image_rgb(path);
+        float *p = (float *) malloc(im.data.size() * sizeof(float));
+        if (!p) throw std::runtime_error("out of memory");
+        memcpy(p, im.data.data(), im.data.size() * sizeof(float));
+        *width = im.width; *height = im.height; *channels = im.channels; *data = p;
+        return LRT_OK;
+    LRT_CATCH
+}
+
+void lrt_image_free(float *data) { free(data); }
+
+lrt_status lrt_image_write_exr(const char *path, int width, int height, int channels, const float *data) {
+    if (!path || !data) return fail(LRT_ERR_INVALID, "lrt_image_write_exr: null argument");
+    LRT_TRY
+        write_exr(path, width, height, channels, data);
+        return LRT_OK;
+    LRT_CATCH
 }
 
 } // extern "C"

@@ -1,0 +1,207 @@
+"""CPU tests of the host side: the C-ABI library loads and exports every symbol the
+header declares, scene loading (XML subset, dict, from-buffers), image readers,
+parameter plumbing and error behaviour.  No compute call is made (no GPU)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, LIVER_XML, PARENCHYMA_XML, MULTIMESH_XML
+
+
+def test_library_exports_every_declared_symbol(mi):
+    from liverrenderer_amd import _lib
+    header = open(os.path.join(ROOT, "include", "liverrt.h")).read()
+    declared = re.findall(r"LRT_API\s+[\w\s\*]+?\b(lrt_\w+)\s*\(", header)
+    assert len(declared) >= 15
+    L = _lib.lib()
+    for name in declared:
+        assert hasattr(L, name), f"{name} is declared in include/liverrt.h but not exported"
+    assert sorted(set(declared)) == sorted(_lib.EXPORTED_SYMBOLS)
+    assert L.lrt_version() >= 100
+
+
+def test_ctypes_struct_layout_matches_header(mi):
+    """sizeof() of the mirrored structs must match what the C compiler lays out."""
+    import subprocess, tempfile
+    from liverrenderer_amd import _lib
+    src = '#include "liverrt.h"\n#include <stdio.h>\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",' \
+          'sizeof(lrt_shape_desc),sizeof(lrt_texture_desc),sizeof(lrt_bsdf_desc),sizeof(lrt_medium_desc),sizeof(lrt_emitter_desc),' \
+          'sizeof(lrt_sensor_desc),sizeof(lrt_film_desc),sizeof(lrt_integrator_desc),sizeof(lrt_scene_desc),sizeof(lrt_render_opts),' \
+          'sizeof(lrt_render_stats),sizeof(lrt_param_grads));return 0;}'
+    with tempfile.TemporaryDirectory() as td:
+        open(os.path.join(td, "s.c"), "w").write(src)
+        subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(td, "s.c"), "-o", os.path.join(td, "s")], check=True)
+        sizes = [int(x) for x in subprocess.run([os.path.join(td, "s")], capture_output=True, text=True, check=True).stdout.split()]
+    mirrors = [_lib.ShapeDesc, _lib.TextureDesc, _lib.BsdfDesc, _lib.MediumDesc, _lib.EmitterDesc, _lib.SensorDesc, _lib.FilmDesc,
+               _lib.IntegratorDesc, _lib.SceneDesc, _lib.RenderOpts, _lib.RenderStats, _lib.ParamGrads]
+    assert sizes == [C.sizeof(m) for m in mirrors]
+
+
+def test_variant_api(mi):
+    assert mi.variants() == ["hip_ad_rgb"] and mi.variant() == "hip_ad_rgb"
+    mi.set_variant("hip_ad_rgb")
+    with pytest.raises(ImportError):
+        mi.set_variant("cuda_ad_rgb")
+
+
+def test_cornell_box_description(mi, cornell):
+    d = cornell.desc
+    assert (d.n_shapes, d.n_faces, d.n_vertices, d.n_emitters, d.n_media) == (8, 36, 72, 1, 0)   # 6 rectangles x 2 + 2 cubes x 12
+    assert (d.film.width, d.film.height, d.film.has_alpha, d.film.rfilter) == (256, 256, 0, 1)
+    assert d.film.rfilter_param == 0.5 and d.sample_count == 64
+    assert (d.integrator.type, d.integrator.max_depth, d.integrator.rr_depth, d.integrator.hide_emitters) == (0, 8, 5, 0)
+    assert d.sensor.fov_x == pytest.approx(39.3077, rel=1e-6) and d.sensor.near_clip == pytest.approx(0.001)
+    light = d.shapes[0]
+    assert light.kind == 1 and light.emitter == 0 and list(d.emitters[0].radiance) == pytest.approx([18.387, 13.9873, 6.75357])
+    # src/shapes/rectangle.cpp:85-160: light = translate(0,.99,.01) * rotate(x,90) * scale(.23,.19,.19)
+    p = np.ctypeslib.as_array(d.positions, (d.n_vertices * 3,)).reshape(-1, 3)
+    assert np.allclose(p[:4, 1], 0.99, atol=1e-6) and np.allclose(np.abs(p[:4, 0]), 0.23, atol=1e-6)
+    n = np.ctypeslib.as_array(d.normals, (d.n_vertices * 3,)).reshape(-1, 3)
+    assert np.allclose(n[:4], [0, -1, 0], atol=1e-6)
+    f = np.ctypeslib.as_array(d.faces, (d.n_faces * 3,)).reshape(-1, 3)
+    assert f[:2].tolist() == [[1, 2, 0], [1, 3, 2]]
+    # shared 'white' BSDF is instantiated once
+    assert d.n_bsdfs == 3 and len({d.shapes[i].bsdf for i in range(8)}) == 3
+
+
+def test_liver_scene_description(mi):
+    sc = mi.load_file(LIVER_XML, integrator="volpath")
+    d = sc.desc
+    assert (d.n_vertices, d.n_faces, d.n_shapes) == (1202, 2400, 1)
+    assert (d.film.width, d.film.height, d.film.has_alpha, d.film.rfilter, d.sample_count) == (854, 480, 1, 0, 256)
+    assert (d.integrator.type, d.integrator.max_depth) == (1, 12)
+    m = d.media[0]
+    # `liver` read as the base-class homogeneous medium (src/media/liver.cpp:139-141,194)
+    assert m.id == b"LiverMedium" and list(m.sigma_t) == [1, 1, 1] and list(m.albedo) == [0.75] * 3 and m.scale == 1
+    assert m.has_spectral_extinction == 1 and m.sample_emitters == 1 and m.phase == 0
+    s = d.shapes[0]
+    assert s.interior_medium == 0 and s.exterior_medium == -1 and s.has_normals and s.has_texcoords
+    b = d.bsdfs[s.bsdf]
+    assert b.type == 2 and b.scale == pytest.approx(0.005) and d.bsdfs[b.nested].type == 1
+    assert d.bsdfs[b.nested].eta == pytest.approx(1.38)
+    e = d.emitters[0]
+    assert e.type == 1 and (e.width, e.height) == (1024, 512) and e.scale == 2.5
+    p = np.ctypeslib.as_array(d.positions, (d.n_vertices * 3,)).reshape(-1, 3)
+    assert np.allclose(p.min(0), [-59.143543, -32.923416, -61.761173]) and np.allclose(p.max(0), [-27.582193, -2.777367, -23.66299])
+    # defines override the file's <default>s
+    sc2 = mi.load_file(LIVER_XML, integrator="volpath", spp=512, res_width=1920, res_height=1080)
+    assert (sc2.desc.film.width, sc2.desc.film.height, sc2.desc.sample_count) == (1920, 1080, 512)
+
+
+def test_bump_texture_is_linearised_fp16(mi):
+    """src/textures/bitmap.cpp:268-283: 8-bit input -> sRGB-to-linear -> fp16 storage."""
+    from PIL import Image
+    sc = mi.load_file(LIVER_XML, integrator="volpath")
+    d = sc.desc
+    t = [d.textures[i] for i in range(d.n_textures) if d.textures[i].type == 2][0]
+    assert (t.width, t.height, t.channels) == (587, 418, 3)
+    data = np.ctypeslib.as_array(t.data, (t.height, t.width, 3))
+    png = np.asarray(Image.open(os.path.join(os.path.dirname(LIVER_XML), "tissue_n.png")))[..., :3].astype(np.float32) / np.float32(255)
+    lin = np.where(png <= 0.04045, png / 12.92, ((png + 0.055) / 1.055) ** 2.4).astype(np.float32)
+    expected = lin.astype(np.float16).astype(np.float32)
+    assert np.abs(data - expected).max() <= np.spacing(np.float16(1.0)) * 1.01     # at most one fp16 ulp (powf vs numpy pow)
+    assert (data == data.astype(np.float16).astype(np.float32)).all()            # exactly representable in fp16
+
+
+def test_exr_and_png_readers_against_reference_pair(mi):
+    """The reference ships cornell_box.exr (PIZ, float32) and its 8-bit sRGB rendition cornell_box.png:
+    decoding the first and tone-mapping must reproduce the second within one code value."""
+    exr = mi.read_image(os.path.join(ROOT, "tests", "golden", "reference_cornell_box.exr"))
+    png = mi.read_image(os.path.join(ROOT, "tests", "golden", "reference_cornell_box.png"))
+    assert exr.shape == (256, 256, 3) and png.shape == (256, 256, 3)
+    srgb = np.where(exr <= 0.0031308, 12.92 * exr, 1.055 * np.clip(exr, 1e-9, None) ** (1 / 2.4) - 0.055)
+    q = np.clip(np.round(srgb * 255), 0, 255)
+    assert np.abs(q - np.round(png * 255)).max() <= 1
+    env = mi.read_image(os.path.join(ROOT, "scenes", "assets", "cavidade_latitude.exr"))      # PIZ, half, RGBA
+    assert env.shape == (512, 1024, 4) and np.isfinite(env).all() and (env[..., 3] == 1).all() and 0 < env[..., :3].min() and env.max() <= 1.0
+
+
+def test_exr_writer_roundtrip(mi, tmp_path):
+    rng = np.random.default_rng(0)
+    for ch in (1, 3, 4):
+        img = rng.random((7, 11, ch)).astype(np.float32)
+        p = tmp_path / f"t{ch}.exr"
+        mi.write_exr(p, img)
+        assert (mi.read_image(p) == img).all()
+
+
+def test_other_scene_files_load(mi):
+    sp = mi.load_file(PARENCHYMA_XML, integrator="volpath"); p = sp.desc       # keep the scene alive: desc is a view
+    assert p.media[0].has_spectral_extinction == 0 and p.media[0].sample_emitters == 0      # src/media/parenchyma.cpp:149-150
+    assert p.film.rfilter == 2 and p.integrator.hide_emitters == 1 and p.emitters[0].type == 2
+    assert p.bsdfs[p.shapes[0].bsdf].eta == pytest.approx(1.38)
+    etas = sorted(p.bsdfs[i].eta for i in range(p.n_bsdfs) if p.bsdfs[i].type == 1)
+    assert etas[-1] == pytest.approx(1.5046 / 1.000277)           # <bsdf type="dielectric"/>: bk7 / air (include/mitsuba/render/ior.h)
+    sm = mi.load_file(MULTIMESH_XML, integrator="path"); m = sm.desc
+    assert m.n_faces == 2400 and m.shapes[0].interior_medium == -1
+
+
+def test_xml_errors(mi):
+    with pytest.raises(RuntimeError, match="unsupported integrator"):
+        mi.load_file(LIVER_XML)                                   # default integrator is the fork's biovolpath
+    with pytest.raises(RuntimeError, match="cannot open"):
+        mi.load_file("/nonexistent/scene.xml")
+    with pytest.raises(RuntimeError, match="undefined parameter"):
+        mi.load_string('<scene version="3.0.0"><integrator type="$foo"/></scene>')
+    with pytest.raises(RuntimeError, match="XML parse error"):
+        mi.load_string('<scene version="3.0.0"><integrator type="path"></scene>')
+    with pytest.raises(RuntimeError, match="no sensor"):
+        mi.load_string('<scene version="3.0.0"><integrator type="path"/></scene>')
+    with pytest.raises(RuntimeError, match="unknown id"):
+        mi.load_string('<scene version="3.0.0"><shape type="cube"><ref id="nope"/></shape></scene>')
+    with pytest.raises(RuntimeError, match="unsupported bsdf"):
+        mi.load_string('<scene version="3.0.0"><bsdf type="roughplastic" id="a"/></scene>')
+    with pytest.raises(RuntimeError, match="rr_depth"):
+        d = mi.cornell_box(); d["integrator"]["rr_depth"] = 0; mi.load_dict(d)
+    with pytest.raises(RuntimeError, match="crop window"):
+        d = mi.cornell_box(); d["sensor"]["film"]["crop_width"] = 500; mi.load_dict(d)
+
+
+def test_transform_composition_order(mi):
+    """src/core/parser.cpp:457-561: XML transform children are applied in document order."""
+    xml = """<scene version="3.0.0"><integrator type="path"/>
+      <sensor type="perspective"><film type="hdrfilm"><integer name="width" value="8"/><integer name="height" value="8"/></film></sensor>
+      <shape type="rectangle"><transform name="to_world"><scale x="2" y="3"/><translate x="10"/><rotate z="1" angle="90"/></transform></shape></scene>"""
+    sc = mi.load_string(xml); d = sc.desc
+    p = np.ctypeslib.as_array(d.positions, (12,)).reshape(4, 3)
+    # (-1,-1,0) -> scale (-2,-3,0) -> translate (8,-3,0) -> rotate 90 about z (3, 8, 0)
+    assert np.allclose(p[0], [3, 8, 0], atol=1e-5)
+    T = mi.ScalarTransform4f
+    m = T().translate([1, 2, 3]).rotate([0, 0, 1], 90).scale([2, 2, 2]).matrix
+    assert np.allclose(m @ [1, 0, 0, 1], [1, 4, 3, 1])
+
+
+def test_traverse_and_param_roundtrip(mi):
+    sc = mi.load_file(LIVER_XML, integrator="volpath")
+    p = mi.traverse(sc)
+    assert set(p.keys()) == {"LiverMedium.sigma_t.value", "LiverMedium.albedo.value", "LiverMedium.scale", "LiverMedium.phase_function.g"}
+    p["LiverMedium.sigma_t.value"] = [0.5, 0.25, 0.8]
+    p["LiverMedium.albedo.value"] = 0.6
+    p.update()
+    assert list(sc.param_get("LiverMedium.sigma_t.value")) == [0.5, 0.25, 0.8] and list(sc.param_get("LiverMedium.albedo.value")) == [np.float32(0.6)] * 3
+    with pytest.raises(KeyError):
+        p["LiverMedium.nope"] = 1
+    with pytest.raises(RuntimeError, match="asymmetry"):
+        sc.param_set("LiverMedium.phase_function.g", 1.5)
+
+
+def test_render_without_gpu_fails_loudly(mi, cornell):
+    """There is no CPU fallback: on a machine without a HIP device the render call must raise."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError, match="no HIP device|hip"):
+        cornell.render(spp=1)
+    with pytest.raises(RuntimeError):
+        cornell.trace(np.zeros((1, 3), np.float32), np.array([[0, 0, 1]], np.float32))
+
+
+def test_scene_from_buffers_validation(mi):
+    v = np.zeros((3, 3), np.float32)
+    with pytest.raises(RuntimeError, match="invalid vertex"):
+        mi.scene_from_buffers(v, np.array([[0, 1, 7]], np.uint32))
+    sc = mi.scene_from_buffers(v, np.array([[0, 1, 2]], np.uint32), constant_radiance=(1, 2, 3))
+    assert sc.desc.n_emitters == 1 and list(sc.desc.emitters[0].radiance) == [1, 2, 3]
