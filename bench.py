@@ -36,7 +36,7 @@ def parse():
     p.add_argument("--scene", default=os.path.join(ROOT, "scenes", "Liver-SingleMesh", "mitsuba3", "scene.xml"))
     p.add_argument("--integrator", default="volpath")
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--cpu-spp", type=int, default=1, help="spp of the bounded CPU-baseline sample")
+    p.add_argument("--cpu-spp", type=int, default=0, help="spp of the bounded CPU-baseline sample (0: calibrate to ~15 s)")
     return p.parse_args()
 
 
@@ -124,9 +124,13 @@ def main():
         # ---- CPU baseline: the oracle (our restatement of the reference's CPU path) on the host cores,
         # same scene/resolution at a reduced spp, and the GPU-vs-oracle RMSE at that spp (same seed).
         import orc
+        cores = os.cpu_count() or 1
+        if a.cpu_spp <= 0:                       # calibrate on 1 spp so that the sample takes ~15 s of wall time
+            cs = mi.load_file(a.scene, integrator=a.integrator, spp=1, res_width=a.width, res_height=a.height)
+            t1 = time.perf_counter(); orc.OrcScene(cs).render(threads=cores, spp=1, seed=0); c1 = time.perf_counter() - t1
+            a.cpu_spp = int(min(a.spp, max(1, round(15.0 / max(c1, 1e-3)))))
         cs = mi.load_file(a.scene, integrator=a.integrator, spp=a.cpu_spp, res_width=a.width, res_height=a.height)
         o = orc.OrcScene(cs)
-        cores = os.cpu_count() or 1
         t1 = time.perf_counter()
         cimg = o.render(threads=cores, spp=a.cpu_spp, seed=0)
         ct = time.perf_counter() - t1

@@ -10,6 +10,8 @@
 #include <algorithm>
 #include <stdexcept>
 #include <string>
+#include <cstdio>
+#include <cstdlib>
 
 namespace lrt {
 
@@ -361,9 +363,19 @@ static void run_wavefront(DeviceScene *D, const lrt_scene_desc &d, const Resolve
             launches.emplace_back(a, b);
             HIP_CHECK(hipMemcpyAsync(D->h_counters, D->counters, sizeof(DCounters), hipMemcpyDeviceToHost, st));
             HIP_CHECK(hipStreamSynchronize(st));
-            n_iter += n;
+            // path.cpp:103-104 returns before the loop when max_depth == 0: that launch only retires the lanes
+            if (!(O.integrator == LRT_INTEGRATOR_PATH && O.max_depth == 0)) n_iter += n;
             n = D->h_counters->n_out;
             cur ^= 1;
+            if (getenv("LRT_DEBUG_STATE") && n > 0) {      // developer aid: dump the first surviving path records
+                float4 a[2], b[2], c[2], dd[2], e[2];
+                (void) hipMemcpy(a, D->q[cur].o_maxt, 32, hipMemcpyDeviceToHost); (void) hipMemcpy(b, D->q[cur].d_eta, 32, hipMemcpyDeviceToHost);
+                (void) hipMemcpy(c, D->q[cur].tp_pdf, 32, hipMemcpyDeviceToHost); (void) hipMemcpy(dd, D->q[cur].res_flags, 32, hipMemcpyDeviceToHost);
+                (void) hipMemcpy(e, D->q[cur].lp_lane, 32, hipMemcpyDeviceToHost);
+                uint32_t fl, ln; memcpy(&fl, &dd[0].w, 4); memcpy(&ln, &e[0].w, 4);
+                fprintf(stderr, "[lrt] n=%u o=(%g %g %g) maxt=%g d=(%g %g %g) eta=%g tp=(%g %g %g) pdf=%g res=(%g %g %g) flags=%08x lane=%u\n", n,
+                        a[0].x, a[0].y, a[0].z, a[0].w, b[0].x, b[0].y, b[0].z, b[0].w, c[0].x, c[0].y, c[0].z, c[0].w, dd[0].x, dd[0].y, dd[0].z, fl, ln);
+            }
         }
     }
     HIP_CHECK(hipEventRecord(e_end, st));

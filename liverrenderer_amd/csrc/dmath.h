@@ -196,16 +196,19 @@ DEV float mean3(V3 a) { return (a.x + a.y + a.z) * (1.f / 3.f); }
 DEV float luminance(V3 c) { return c.x * 0.212671f + c.y * 0.715160f + c.z * 0.072169f; }
 DEV float idx3(V3 v, uint32_t c) { return c == 0 ? v.x : (c == 1 ? v.y : v.z); }
 
-DEV void coordinate_system(V3 n, V3 *s, V3 *t) {
+struct Basis { V3 s, t; };
+DEV Basis coordinate_system(V3 n) {
     float sign = signf_(n.z), a = -rcp(sign + n.z), b = n.x * n.y * a;
-    *s = V3(mulsign(sqr(n.x) * a, n.z) + 1.f, mulsign(b, n.z), mulsign_neg(n.x, n.z));
-    *t = V3(b, fma_(n.y, n.y * a, sign), -n.y);
+    Basis r;
+    r.s = V3(mulsign(sqr(n.x) * a, n.z) + 1.f, mulsign(b, n.z), mulsign_neg(n.x, n.z));
+    r.t = V3(b, fma_(n.y, n.y * a, sign), -n.y);
+    return r;
 }
 
 struct Frame {
     V3 s, t, n;
     DEV Frame() {}
-    DEV explicit Frame(V3 v) : n(v) { coordinate_system(v, &s, &t); }
+    DEV explicit Frame(V3 v) : n(v) { Basis b = coordinate_system(v); s = b.s; t = b.t; }
     DEV V3 to_local(V3 v) const { return V3(dot(v, s), dot(v, t), dot(v, n)); }
     DEV V3 to_world(V3 v) const { return fma3(n, v.z, fma3(t, v.y, s * v.x)); }
 };

@@ -91,51 +91,54 @@ DEV Hit trace(const DScene &sc, const Ray &r, int *__restrict__ stack /* &lds[th
 // --------------------------------------------------- surface interaction
 // src/render/mesh.cpp:1489-1659 + include/mitsuba/render/interaction.h:290-300,516-536
 DEV SI compute_si(const DScene &sc, const Ray &r, const Hit &h) {
-    SI si;
-    si.valid = h.prim != 0xffffffffu;
-    if (!si.valid) {
-        si.t = kInf; si.wi = -r.d; si.shape = 0xffffffffu; si.prim = 0xffffffffu;
-        si.p = V3(0.f); si.n = V3(0.f); si.uv = { 0.f, 0.f }; si.dp_du = V3(0.f); si.dp_dv = V3(0.f);
-        si.sh.s = V3(0.f); si.sh.t = V3(0.f); si.sh.n = V3(0.f);
-        return si;
-    }
-    uint32_t f = h.prim, shp = sc.face_shape[f];
-    const DShape sd = sc.shapes[shp];
-    uint32_t i0 = sc.faces[3 * f], i1 = sc.faces[3 * f + 1], i2 = sc.faces[3 * f + 2];
-    V3 p0(sc.positions[3 * i0], sc.positions[3 * i0 + 1], sc.positions[3 * i0 + 2]);
-    V3 p1(sc.positions[3 * i1], sc.positions[3 * i1 + 1], sc.positions[3 * i1 + 2]);
-    V3 p2(sc.positions[3 * i2], sc.positions[3 * i2 + 1], sc.positions[3 * i2 + 2]);
-    float b1 = h.u, b2 = h.v, b0 = 1.f - b1 - b2;
-    si.t = h.t; si.prim = f; si.shape = shp;
-    si.p = V3(fma_(p0.x, b0, fma_(p1.x, b1, p2.x * b2)), fma_(p0.y, b0, fma_(p1.y, b1, p2.y * b2)), fma_(p0.z, b0, fma_(p1.z, b1, p2.z * b2)));
-    V3 dp0 = p1 - p0, dp1 = p2 - p0;
-    si.n = normalize(cross(dp0, dp1));
-    si.uv = { b1, b2 };
-    coordinate_system(si.n, &si.dp_du, &si.dp_dv);
-    if (sd.has_texcoords) {
-        V2 uv0 = { sc.texcoords[2 * i0], sc.texcoords[2 * i0 + 1] }, uv1 = { sc.texcoords[2 * i1], sc.texcoords[2 * i1 + 1] },
-           uv2 = { sc.texcoords[2 * i2], sc.texcoords[2 * i2 + 1] };
-        si.uv = { fma_(uv2.x, b2, fma_(uv1.x, b1, uv0.x * b0)), fma_(uv2.y, b2, fma_(uv1.y, b1, uv0.y * b0)) };
-        V2 duv0 = { uv1.x - uv0.x, uv1.y - uv0.y }, duv1 = { uv2.x - uv0.x, uv2.y - uv0.y };
-        float det = fma_(duv0.x, duv1.y, -(duv0.y * duv1.x)), inv_det = rcp(det);
-        if (det != 0.f) {
-            si.dp_du = V3(fma_(duv1.y, dp0.x, -(duv0.y * dp1.x)), fma_(duv1.y, dp0.y, -(duv0.y * dp1.y)), fma_(duv1.y, dp0.z, -(duv0.y * dp1.z))) * inv_det;
-            si.dp_dv = V3(fma_(-duv1.x, dp0.x, duv0.x * dp1.x), fma_(-duv1.x, dp0.y, duv0.x * dp1.y), fma_(-duv1.x, dp0.z, duv0.x * dp1.z)) * inv_det;
+    const bool valid = h.prim != 0xffffffffu;
+    // every field is written through plain locals (no member addresses escape): keeps the record in VGPRs
+    float t = kInf; V3 p(0.f), n(0.f), shn(0.f), shs(0.f), sht(0.f), dp_du(0.f), dp_dv(0.f), wi = -r.d;
+    V2 uv = { 0.f, 0.f }; uint32_t f = 0xffffffffu, shp = 0xffffffffu;
+    if (valid) {
+        f = h.prim; shp = sc.face_shape[f];
+        const DShape sd = sc.shapes[shp];
+        uint32_t i0 = sc.faces[3 * f], i1 = sc.faces[3 * f + 1], i2 = sc.faces[3 * f + 2];
+        V3 p0(sc.positions[3 * i0], sc.positions[3 * i0 + 1], sc.positions[3 * i0 + 2]);
+        V3 p1(sc.positions[3 * i1], sc.positions[3 * i1 + 1], sc.positions[3 * i1 + 2]);
+        V3 p2(sc.positions[3 * i2], sc.positions[3 * i2 + 1], sc.positions[3 * i2 + 2]);
+        float b1 = h.u, b2 = h.v, b0 = 1.f - b1 - b2;
+        t = h.t;
+        p = V3(fma_(p0.x, b0, fma_(p1.x, b1, p2.x * b2)), fma_(p0.y, b0, fma_(p1.y, b1, p2.y * b2)), fma_(p0.z, b0, fma_(p1.z, b1, p2.z * b2)));
+        V3 dp0 = p1 - p0, dp1 = p2 - p0;
+        n = normalize(cross(dp0, dp1));
+        uv = { b1, b2 };
+        Basis bs = coordinate_system(n);
+        dp_du = bs.s; dp_dv = bs.t;
+        if (sd.has_texcoords) {
+            V2 uv0 = { sc.texcoords[2 * i0], sc.texcoords[2 * i0 + 1] }, uv1 = { sc.texcoords[2 * i1], sc.texcoords[2 * i1 + 1] },
+               uv2 = { sc.texcoords[2 * i2], sc.texcoords[2 * i2 + 1] };
+            uv = { fma_(uv2.x, b2, fma_(uv1.x, b1, uv0.x * b0)), fma_(uv2.y, b2, fma_(uv1.y, b1, uv0.y * b0)) };
+            V2 duv0 = { uv1.x - uv0.x, uv1.y - uv0.y }, duv1 = { uv2.x - uv0.x, uv2.y - uv0.y };
+            float det = fma_(duv0.x, duv1.y, -(duv0.y * duv1.x)), inv_det = rcp(det);
+            if (det != 0.f) {
+                dp_du = V3(fma_(duv1.y, dp0.x, -(duv0.y * dp1.x)), fma_(duv1.y, dp0.y, -(duv0.y * dp1.y)), fma_(duv1.y, dp0.z, -(duv0.y * dp1.z))) * inv_det;
+                dp_dv = V3(fma_(-duv1.x, dp0.x, duv0.x * dp1.x), fma_(-duv1.x, dp0.y, duv0.x * dp1.y), fma_(-duv1.x, dp0.z, duv0.x * dp1.z)) * inv_det;
+            }
         }
+        if (sd.has_normals) {
+            V3 n0(sc.normals[3 * i0], sc.normals[3 * i0 + 1], sc.normals[3 * i0 + 2]);
+            V3 n1(sc.normals[3 * i1], sc.normals[3 * i1 + 1], sc.normals[3 * i1 + 2]);
+            V3 n2(sc.normals[3 * i2], sc.normals[3 * i2 + 1], sc.normals[3 * i2 + 2]);
+            V3 ni(fma_(n2.x, b2, fma_(n1.x, b1, n0.x * b0)), fma_(n2.y, b2, fma_(n1.y, b1, n0.y * b0)), fma_(n2.z, b2, fma_(n1.z, b1, n0.z * b0)));
+            float il = rsqrt_(squared_norm(ni));
+            shn = ni * il;
+        } else shn = n;
+        if (sd.flip_normals) { n = V3(-n.x, -n.y, -n.z); shn = V3(-shn.x, -shn.y, -shn.z); }
+        shs = normalize(fma3(shn, -dot(shn, dp_du), dp_du));
+        if (dp_du.x == 0.f && dp_du.y == 0.f && dp_du.z == 0.f) shs = coordinate_system(shn).s;
+        sht = cross(shn, shs);
+        V3 md(-r.d.x, -r.d.y, -r.d.z);
+        wi = V3(dot(md, shs), dot(md, sht), dot(md, shn));
     }
-    if (sd.has_normals) {
-        V3 n0(sc.normals[3 * i0], sc.normals[3 * i0 + 1], sc.normals[3 * i0 + 2]);
-        V3 n1(sc.normals[3 * i1], sc.normals[3 * i1 + 1], sc.normals[3 * i1 + 2]);
-        V3 n2(sc.normals[3 * i2], sc.normals[3 * i2 + 1], sc.normals[3 * i2 + 2]);
-        V3 n(fma_(n2.x, b2, fma_(n1.x, b1, n0.x * b0)), fma_(n2.y, b2, fma_(n1.y, b1, n0.y * b0)), fma_(n2.z, b2, fma_(n1.z, b1, n0.z * b0)));
-        float il = rsqrt_(squared_norm(n));
-        si.sh.n = n * il;
-    } else si.sh.n = si.n;
-    if (sd.flip_normals) { si.n = -si.n; si.sh.n = -si.sh.n; }
-    si.sh.s = normalize(fma3(si.sh.n, -dot(si.sh.n, si.dp_du), si.dp_du));
-    if (si.dp_du.x == 0.f && si.dp_du.y == 0.f && si.dp_du.z == 0.f) { V3 tmp; coordinate_system(si.sh.n, &si.sh.s, &tmp); }
-    si.sh.t = cross(si.sh.n, si.sh.s);
-    si.wi = si.sh.to_local(-r.d);
+    SI si;
+    si.valid = valid; si.t = t; si.p = p; si.n = n; si.sh.s = shs; si.sh.t = sht; si.sh.n = shn; si.uv = uv;
+    si.dp_du = dp_du; si.dp_dv = dp_dv; si.wi = wi; si.prim = f; si.shape = shp;
     return si;
 }
 
@@ -211,7 +214,7 @@ DEV V2 tex_eval_1_grad(const DScene &sc, int tex, const SI &si) {
 
 // ----------------------------------------------------------------- BSDFs
 enum { F_DELTA = 1, F_SMOOTH = 2, F_NULL = 4 };
-struct BSDFSample { V3 wo; float pdf, eta; int type; };
+struct BSDFSample { V3 wo; float pdf, eta; int type; V3 weight; };
 
 // include/mitsuba/render/fresnel.h:35-73
 DEV void fresnel(float cos_theta_i, float eta, float *r, float *cos_theta_t, float *eta_it, float *eta_ti) {
@@ -251,27 +254,34 @@ DEV float shadow_terminator(V3 pn, V3 wo) {       // src/bsdfs/normalmap_helpers
 }
 
 // Leaf BSDFs (diffuse / dielectric / null), evaluated in the frame `wi` is given in.
-DEV void leaf_sample(const DScene &sc, const DBsdf &B, const SI &si, V3 wi, float s1, float s2x, float s2y, BSDFSample *bs, V3 *weight) {
-    bs->wo = V3(0.f); bs->pdf = 0.f; bs->eta = 0.f; bs->type = 0; *weight = V3(0.f);
+DEV BSDFSample leaf_sample(const DScene &sc, const DBsdf &B, const SI &si, V3 wi, float s1, float s2x, float s2y) {
+    BSDFSample bs;
+    bs.wo = V3(0.f); bs.pdf = 0.f; bs.eta = 0.f; bs.type = 0; bs.weight = V3(0.f);       // dr::zeros<BSDFSample3f>
     if (B.type == LRT_BSDF_DIFFUSE) {               // src/bsdfs/diffuse.cpp sample()
-        if (!(wi.z > 0.f)) return;
-        bs->wo = square_to_cosine_hemisphere(s2x, s2y);
-        bs->pdf = kInvPi * bs->wo.z; bs->eta = 1.f; bs->type = F_SMOOTH;
-        if (bs->pdf > 0.f) *weight = tex_eval(sc, B.reflectance, si);
+        if (wi.z > 0.f) {
+            bs.wo = square_to_cosine_hemisphere(s2x, s2y);
+            bs.pdf = kInvPi * bs.wo.z; bs.eta = 1.f; bs.type = F_SMOOTH;
+            if (bs.pdf > 0.f) bs.weight = tex_eval(sc, B.reflectance, si);
+        }
     } else if (B.type == LRT_BSDF_DIELECTRIC) {     // src/bsdfs/dielectric.cpp:230-367
         float r_i, ctt, eta_it, eta_ti;
         fresnel(wi.z, B.eta, &r_i, &ctt, &eta_it, &eta_ti);
         float t_i = 1.f - r_i;
         bool sel_r = s1 <= r_i;
-        bs->pdf = sel_r ? r_i : t_i;
-        bs->type = F_DELTA;
-        bs->wo = sel_r ? V3(-wi.x, -wi.y, wi.z) : V3(-eta_ti * wi.x, -eta_ti * wi.y, ctt);
-        bs->eta = sel_r ? 1.f : eta_it;
-        *weight = V3(1.f);
-        if (!sel_r) *weight = *weight * sqr(eta_ti);
+        bs.pdf = sel_r ? r_i : t_i;
+        bs.type = F_DELTA;
+        bs.wo = sel_r ? V3(-wi.x, -wi.y, wi.z) : V3(-eta_ti * wi.x, -eta_ti * wi.y, ctt);
+        bs.eta = sel_r ? 1.f : eta_it;
+        bs.weight = V3(1.f);
+        if (!sel_r) bs.weight = bs.weight * sqr(eta_ti);
     } else {                                       // src/bsdfs/null.cpp sample()
-        bs->wo = -wi; bs->type = F_NULL; bs->eta = 1.f; bs->pdf = 1.f; *weight = V3(1.f);
+        // ROCm 7.2 / gfx950 code generation drops the negated z component when this branch's values meet the
+        // other branches' phis (reproducer: scripts/dbg/t_null.hip); the empty asm keeps them in their own VGPRs.
+        float nx = -wi.x, ny = -wi.y, nz = -wi.z;
+        asm volatile("" : "+v"(nx), "+v"(ny), "+v"(nz));
+        bs.wo = V3(nx, ny, nz); bs.type = F_NULL; bs.eta = 1.f; bs.pdf = 1.f; bs.weight = V3(1.f);
     }
+    return bs;
 }
 DEV V3 leaf_eval(const DScene &sc, const DBsdf &B, const SI &si, V3 wi, V3 wo) {
     if (B.type == LRT_BSDF_DIFFUSE) {
@@ -285,19 +295,21 @@ DEV float leaf_pdf(const DBsdf &B, V3 wi, V3 wo) {
     return 0.f;
 }
 
-DEV void bsdf_sample(const DScene &sc, int b, const SI &si, float s1, float s2x, float s2y, BSDFSample *bs, V3 *weight) {
+DEV BSDFSample bsdf_sample(const DScene &sc, int b, const SI &si, float s1, float s2x, float s2y) {
     const DBsdf B = sc.bsdfs[b];
     if (B.type == LRT_BSDF_BUMPMAP) {               // src/bsdfs/bumpmap.cpp:138-162
         Frame pf = bump_frame(sc, B, si);
         V3 pwi = pf.to_local(si.wi);
-        V3 w; leaf_sample(sc, sc.bsdfs[B.nested], si, pwi, s1, s2x, s2y, bs, &w);
-        bool active = any_nonzero(w);
-        V3 pwo = pf.to_world(bs->wo);
-        active = active && (bs->wo.z * pwo.z > 0.f);
-        bs->wo = pwo;
-        w = w * shadow_terminator(pf.n, bs->wo);
-        *weight = active ? w : V3(0.f);
-    } else leaf_sample(sc, B, si, si.wi, s1, s2x, s2y, bs, weight);
+        BSDFSample bs = leaf_sample(sc, sc.bsdfs[B.nested], si, pwi, s1, s2x, s2y);
+        bool active = any_nonzero(bs.weight);
+        V3 pwo = pf.to_world(bs.wo);
+        active = active && (bs.wo.z * pwo.z > 0.f);
+        bs.wo = pwo;
+        V3 w = bs.weight * shadow_terminator(pf.n, bs.wo);
+        bs.weight = active ? w : V3(0.f);
+        return bs;
+    }
+    return leaf_sample(sc, B, si, si.wi, s1, s2x, s2y);
 }
 DEV V3 bsdf_eval(const DScene &sc, int b, const SI &si, V3 wo) {
     const DBsdf B = sc.bsdfs[b];

@@ -127,12 +127,16 @@ DEV void finish_path(const DScene &sc, const DRenderParams &rp, float *__restric
     const DFilm &F = sc.film;
     int px, py; lane_to_pixel(sc, rp, lane, &px, &py);
     const int C = F.channels;
-    float vals[5]; int k = 0;
-    vals[k++] = L.x; vals[k++] = L.y; vals[k++] = L.z; if (F.has_alpha) vals[k++] = valid ? 1.f : 0.f; vals[k++] = 1.f;
+    const float alpha = valid ? 1.f : 0.f;
+    auto splat = [&](float *p, float w) {
+        atomicAdd(p + 0, L.x * w); atomicAdd(p + 1, L.y * w); atomicAdd(p + 2, L.z * w);
+        if (F.has_alpha) { atomicAdd(p + 3, alpha * w); atomicAdd(p + 4, 1.f * w); } else atomicAdd(p + 3, 1.f * w);
+    };
     if (F.rfilter == LRT_RFILTER_BOX) {
         int x = px - F.crop_offset_x, y = py - F.crop_offset_y;
         float *p = film + ((size_t) y * F.width + x) * C;
-        for (int c = 0; c < C; ++c) atomicAdd(p + c, vals[c]);
+        atomicAdd(p + 0, L.x); atomicAdd(p + 1, L.y); atomicAdd(p + 2, L.z);
+        if (F.has_alpha) { atomicAdd(p + 3, alpha); atomicAdd(p + 4, 1.f); } else atomicAdd(p + 3, 1.f);
         return;
     }
     PCG32 rng = lane_rng_fresh(rp.seed_value, lane);                                 // the pixel jitter is the stream's first two draws
@@ -150,8 +154,7 @@ DEV void finish_path(const DScene &sc, const DRenderParams &rp, float *__restric
             if (x < 0 || x >= F.width) continue;
             float w = wy * rfilter_eval(F, relx + (float) xs);
             if (w == 0.f) continue;
-            float *p = film + ((size_t) y * F.width + x) * C;
-            for (int c = 0; c < C; ++c) atomicAdd(p + c, vals[c] * w);
+            splat(film + ((size_t) y * F.width + x) * C, w);
         }
     }
 }
@@ -346,9 +349,8 @@ DEV bool volpath_iteration(const DScene &sc, const DRenderParams &rp, PathState 
             result = result + c;
         }
         float s1 = rng.next(), s2x = rng.next(), s2y = rng.next();
-        BSDFSample bs; V3 bsdf_val;
-        bsdf_sample(sc, b, si, s1, s2x, s2y, &bs, &bsdf_val);
-        throughput = throughput * bsdf_val;
+        const BSDFSample bs = bsdf_sample(sc, b, si, s1, s2x, s2y);
+        throughput = throughput * bs.weight;
         eta *= bs.eta;
         ray = spawn_ray(si.p, si.n, si.sh.to_world(bs.wo));
         bool non_null = !(bs.type & F_NULL);
@@ -424,8 +426,8 @@ DEV bool path_iteration(const DScene &sc, const DRenderParams &rp, PathState &s,
     float s1 = rng.next(), s2x = rng.next(), s2y = rng.next();
     V3 bsdf_val = bsdf_eval(sc, b, si, wo);
     float bpdf = bsdf_pdf(sc, b, si, wo);
-    BSDFSample bs; V3 bsdf_weight;
-    bsdf_sample(sc, b, si, s1, s2x, s2y, &bs, &bsdf_weight);
+    const BSDFSample bs = bsdf_sample(sc, b, si, s1, s2x, s2y);
+    const V3 bsdf_weight = bs.weight;
     if (active_em) {
         float mis_em = ds.delta ? 1.f : mis_weight(ds.pdf, bpdf);
         V3 c = bsdf_val * em_weight * mis_em;
