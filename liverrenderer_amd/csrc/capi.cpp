@@ -128,7 +128,7 @@ lrt_status lrt_render_backward(lrt_scene *scene, const lrt_render_opts *opts, co
     if (!scene || !grad_image || !out) return fail(LRT_ERR_INVALID, "lrt_render_backward: null argument");
     LRT_TRY
         ensure_device(scene, opts ? opts->device : 0);
-        device_render_backward(scene->dev, scene->st.desc, opts, grad_image, out);
+        device_render_backward(scene->dev, scene->st.desc, opts, grad_image, out, scene->stats);
         return LRT_OK;
     LRT_CATCH
 }

@@ -3,7 +3,7 @@
 // that the rest of the library is plain host C++.
 #include "host_scene.h"
 #include "device_scene.h"
-#include "kernels.h"
+#include "kernels_prb.h"
 #include "bvh.h"
 #include <cmath>
 #include <cstring>
@@ -32,6 +32,8 @@ struct DeviceScene {
     // wavefront workspace
     uint32_t capacity = 0;
     DPathStreams q[2]{};
+    float4 *dl[2] = { nullptr, nullptr }; float4 *L_buf = nullptr; uint32_t prb_capacity = 0;   // PRB: delta_L streams, primal radiance
+    double *d_grads = nullptr; float *wfilm = nullptr; size_t wfilm_floats = 0; float *grad_image = nullptr; size_t grad_floats = 0;
     DCounters *counters = nullptr;
     DCounters *h_counters = nullptr;       // pinned
     float *film = nullptr; size_t film_floats = 0;
@@ -148,6 +150,7 @@ static void upload_media(DeviceScene *D, const lrt_scene_desc &d) {
         const lrt_medium_desc &M = d.media[i]; DMedium &o = D->h_media[i];
         for (int k = 0; k < 3; ++k) { o.sigma_t[k] = M.sigma_t[k] * M.scale; o.albedo[k] = M.albedo[k]; }   // homogeneous.cpp:121-126 eval_sigmat
         o.has_spectral_extinction = M.has_spectral_extinction; o.sample_emitters = M.sample_emitters; o.phase = M.phase; o.g = M.g;
+        o.scale = M.scale; o.pad = 0.f;
     }
     HIP_CHECK(hipMemcpyAsync(D->d_media, D->h_media.data(), D->h_media.size() * sizeof(DMedium), hipMemcpyHostToDevice, D->stream));
 }
@@ -302,7 +305,6 @@ struct ResolvedOpts { int integrator, max_depth, rr_depth, hide_emitters; uint32
 static ResolvedOpts resolve(const lrt_scene_desc &d, const lrt_render_opts *o) {
     ResolvedOpts r;
     r.integrator = (o && o->integrator >= 0) ? o->integrator : d.integrator.type;
-    if (r.integrator == LRT_INTEGRATOR_PRBVOLPATH) r.integrator = LRT_INTEGRATOR_VOLPATH;
     r.max_depth = (o && o->max_depth != -2) ? o->max_depth : d.integrator.max_depth;
     r.rr_depth = (o && o->rr_depth >= 0) ? o->rr_depth : d.integrator.rr_depth;
     r.hide_emitters = (o && o->hide_emitters >= 0) ? (o->hide_emitters != 0) : (d.integrator.hide_emitters != 0);
@@ -330,63 +332,97 @@ static void ensure_pixel_list(DeviceScene *D, const ResolvedOpts &O) {
     D->pixel_list_rank = O.tile_rank; D->pixel_list_count = O.tile_count; D->n_owned_pixels = (uint32_t) px.size();
 }
 
-// The wavefront loop.  sample_out != nullptr: per-lane test hook for lanes [lane_begin, lane_begin + n_lanes).
-static void run_wavefront(DeviceScene *D, const lrt_scene_desc &d, const ResolvedOpts &O, uint64_t lane_begin, uint64_t n_lanes,
-                          const uint32_t *pixel_list, float *film, float *sample_out, lrt_render_stats &stats) {
-    hipStream_t st = D->stream;
+static void ensure_prb_workspace(DeviceScene *D, uint32_t capacity) {
+    if (D->prb_capacity >= capacity) return;
+    for (int k = 0; k < 2; ++k) { HIP_CHECK(hipMalloc((void **) &D->dl[k], (size_t) capacity * 16)); D->track(D->dl[k]); }
+    HIP_CHECK(hipMalloc((void **) &D->L_buf, (size_t) capacity * 16)); D->track(D->L_buf);
+    if (!D->d_grads) { HIP_CHECK(hipMalloc((void **) &D->d_grads, 7 * sizeof(double))); D->track(D->d_grads); }
+    D->prb_capacity = capacity;
+}
+
+static DRenderParams make_params(const lrt_scene_desc &d, const ResolvedOpts &O, uint64_t n_lanes) {
     DRenderParams rp{};
     rp.integrator = O.integrator; rp.max_depth = O.max_depth; rp.rr_depth = O.rr_depth; rp.hide_emitters = O.hide_emitters;
     rp.spp = O.spp; rp.log2_spp = ((O.spp & (O.spp - 1)) == 0) ? (uint32_t) __builtin_ctz(O.spp) : 0xffffffffu;
     rp.seed_value = d.sampler_seed + O.seed; rp.tile_rank = O.tile_rank; rp.tile_count = O.tile_count; rp.n_lanes = n_lanes;
-    const uint32_t chunk = (uint32_t) std::min<uint64_t>(n_lanes, 1u << 23);
-    ensure_workspace(D, std::max<uint32_t>(chunk, 1));
-    HIP_CHECK(hipMemsetAsync(D->counters, 0, sizeof(DCounters), st));
-    size_t ev = 0;
-    hipEvent_t e_begin = get_event(D, ev++), e_end = get_event(D, ev++);
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> launches;
-    HIP_CHECK(hipEventRecord(e_begin, st));
-    uint64_t n_iter = 0;
-    for (uint64_t base = 0; base < n_lanes; base += chunk) {
-        uint32_t n = (uint32_t) std::min<uint64_t>(chunk, n_lanes - base);
-        k_raygen<<<(n + LRT_BLOCK - 1) / LRT_BLOCK, LRT_BLOCK, 0, st>>>(D->sc, rp, D->q[0], pixel_list, lane_begin + base, n, 0);
-        int cur = 0;
-        while (n > 0) {
-            HIP_CHECK(hipMemsetAsync(&D->counters->n_out, 0, sizeof(uint32_t), st));
-            hipEvent_t a = get_event(D, ev++), b = get_event(D, ev++);
-            HIP_CHECK(hipEventRecord(a, st));
-            uint32_t grid = (n + LRT_BLOCK - 1) / LRT_BLOCK;
-            if (O.integrator == LRT_INTEGRATOR_PATH)
-                k_iterate<LRT_INTEGRATOR_PATH><<<grid, LRT_BLOCK, 0, st>>>(D->sc, rp, D->q[cur], D->q[cur ^ 1], D->counters, n, film, sample_out, lane_begin);
-            else
-                k_iterate<LRT_INTEGRATOR_VOLPATH><<<grid, LRT_BLOCK, 0, st>>>(D->sc, rp, D->q[cur], D->q[cur ^ 1], D->counters, n, film, sample_out, lane_begin);
-            HIP_CHECK(hipEventRecord(b, st));
-            launches.emplace_back(a, b);
-            HIP_CHECK(hipMemcpyAsync(D->h_counters, D->counters, sizeof(DCounters), hipMemcpyDeviceToHost, st));
-            HIP_CHECK(hipStreamSynchronize(st));
-            // path.cpp:103-104 returns before the loop when max_depth == 0: that launch only retires the lanes
-            if (!(O.integrator == LRT_INTEGRATOR_PATH && O.max_depth == 0)) n_iter += n;
-            n = D->h_counters->n_out;
-            cur ^= 1;
-            if (getenv("LRT_DEBUG_STATE") && n > 0) {      // developer aid: dump the first surviving path records
-                float4 a[2], b[2], c[2], dd[2], e[2];
-                (void) hipMemcpy(a, D->q[cur].o_maxt, 32, hipMemcpyDeviceToHost); (void) hipMemcpy(b, D->q[cur].d_eta, 32, hipMemcpyDeviceToHost);
-                (void) hipMemcpy(c, D->q[cur].tp_pdf, 32, hipMemcpyDeviceToHost); (void) hipMemcpy(dd, D->q[cur].res_flags, 32, hipMemcpyDeviceToHost);
-                (void) hipMemcpy(e, D->q[cur].lp_lane, 32, hipMemcpyDeviceToHost);
-                uint32_t fl, ln; memcpy(&fl, &dd[0].w, 4); memcpy(&ln, &e[0].w, 4);
-                fprintf(stderr, "[lrt] n=%u o=(%g %g %g) maxt=%g d=(%g %g %g) eta=%g tp=(%g %g %g) pdf=%g res=(%g %g %g) flags=%08x lane=%u\n", n,
-                        a[0].x, a[0].y, a[0].z, a[0].w, b[0].x, b[0].y, b[0].z, b[0].w, c[0].x, c[0].y, c[0].z, c[0].w, dd[0].x, dd[0].y, dd[0].z, fl, ln);
-            }
+    return rp;
+}
+
+struct LaunchLog { std::vector<std::pair<hipEvent_t, hipEvent_t>> launches; size_t ev = 0; uint64_t n_iter = 0; };
+
+// Drains one chunk of `n` freshly generated paths sitting in q[0]: launches `iterate(cur, n)` until the queue is empty.
+template <typename Iterate>
+static void drain_chunk(DeviceScene *D, uint32_t n, LaunchLog &log, bool count_iter, Iterate iterate) {
+    hipStream_t st = D->stream;
+    int cur = 0;
+    while (n > 0) {
+        HIP_CHECK(hipMemsetAsync(&D->counters->n_out, 0, sizeof(uint32_t), st));
+        hipEvent_t a = get_event(D, log.ev++), b = get_event(D, log.ev++);
+        HIP_CHECK(hipEventRecord(a, st));
+        iterate(cur, n);
+        HIP_CHECK(hipEventRecord(b, st));
+        log.launches.emplace_back(a, b);
+        HIP_CHECK(hipMemcpyAsync(D->h_counters, D->counters, sizeof(DCounters), hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        if (count_iter) log.n_iter += n;
+        n = D->h_counters->n_out;
+        cur ^= 1;
+        if (getenv("LRT_DEBUG_STATE") && n > 0) {      // developer aid: dump the first surviving path record
+            float4 a4, b4, c4, d4, e4;
+            (void) hipMemcpy(&a4, D->q[cur].o_maxt, 16, hipMemcpyDeviceToHost); (void) hipMemcpy(&b4, D->q[cur].d_eta, 16, hipMemcpyDeviceToHost);
+            (void) hipMemcpy(&c4, D->q[cur].tp_pdf, 16, hipMemcpyDeviceToHost); (void) hipMemcpy(&d4, D->q[cur].res_flags, 16, hipMemcpyDeviceToHost);
+            (void) hipMemcpy(&e4, D->q[cur].lp_lane, 16, hipMemcpyDeviceToHost);
+            uint32_t fl, ln; memcpy(&fl, &d4.w, 4); memcpy(&ln, &e4.w, 4);
+            fprintf(stderr, "[lrt] n=%u o=(%g %g %g) maxt=%g d=(%g %g %g) eta=%g tp=(%g %g %g) pdf=%g res=(%g %g %g) flags=%08x lane=%u\n", n,
+                    a4.x, a4.y, a4.z, a4.w, b4.x, b4.y, b4.z, b4.w, c4.x, c4.y, c4.z, c4.w, d4.x, d4.y, d4.z, fl, ln);
         }
     }
+}
+
+static void finish_stats(DeviceScene *D, LaunchLog &log, hipEvent_t e_begin, hipEvent_t e_end, uint64_t n_lanes, lrt_render_stats &stats) {
+    hipStream_t st = D->stream;
     HIP_CHECK(hipEventRecord(e_end, st));
     HIP_CHECK(hipMemcpyAsync(D->h_counters, D->counters, sizeof(DCounters), hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
     HIP_CHECK(hipGetLastError());
-    stats.n_samples = n_lanes; stats.n_iter = n_iter; stats.n_shadow = D->h_counters->n_shadow; stats.n_launches = launches.size();
+    stats.n_samples = n_lanes; stats.n_iter = log.n_iter; stats.n_shadow = D->h_counters->n_shadow; stats.n_launches = log.launches.size();
     float ms = 0.f; double ksum = 0.0;
-    for (auto &l : launches) { HIP_CHECK(hipEventElapsedTime(&ms, l.first, l.second)); ksum += ms; }
+    for (auto &l : log.launches) { HIP_CHECK(hipEventElapsedTime(&ms, l.first, l.second)); ksum += ms; }
     stats.kernel_ms = ksum;
     HIP_CHECK(hipEventElapsedTime(&ms, e_begin, e_end)); stats.total_ms = ms;
+}
+
+// The wavefront loop.  sample_out != nullptr: per-lane test hook for lanes [lane_begin, lane_begin + n_lanes).
+static void run_wavefront(DeviceScene *D, const lrt_scene_desc &d, const ResolvedOpts &O, uint64_t lane_begin, uint64_t n_lanes,
+                          const uint32_t *pixel_list, float *film, float *sample_out, lrt_render_stats &stats) {
+    hipStream_t st = D->stream;
+    DRenderParams rp = make_params(d, O, n_lanes);
+    const uint32_t chunk = (uint32_t) std::min<uint64_t>(n_lanes, 1u << 23);
+    ensure_workspace(D, std::max<uint32_t>(chunk, 1));
+    const bool prb = O.integrator == LRT_INTEGRATOR_PRBVOLPATH;
+    if (prb) ensure_prb_workspace(D, std::max<uint32_t>(chunk, 1));
+    HIP_CHECK(hipMemsetAsync(D->counters, 0, sizeof(DCounters), st));
+    LaunchLog log;
+    hipEvent_t e_begin = get_event(D, log.ev++), e_end = get_event(D, log.ev++);
+    HIP_CHECK(hipEventRecord(e_begin, st));
+    // path.cpp:103-104 returns before the loop when max_depth == 0: that launch only retires the lanes
+    const bool count_iter = !(O.integrator == LRT_INTEGRATOR_PATH && O.max_depth == 0);
+    for (uint64_t base = 0; base < n_lanes; base += chunk) {
+        uint32_t n = (uint32_t) std::min<uint64_t>(chunk, n_lanes - base);
+        uint32_t grid0 = (n + LRT_BLOCK - 1) / LRT_BLOCK;
+        if (prb) k_raygen_prb<false><<<grid0, LRT_BLOCK, 0, st>>>(D->sc, rp, D->q[0], D->dl[0], pixel_list, lane_begin + base, n, nullptr, nullptr, nullptr);
+        else k_raygen<<<grid0, LRT_BLOCK, 0, st>>>(D->sc, rp, D->q[0], pixel_list, lane_begin + base, n, 0);
+        drain_chunk(D, n, log, count_iter, [&](int cur, uint32_t m) {
+            uint32_t grid = (m + LRT_BLOCK - 1) / LRT_BLOCK;
+            if (prb)
+                k_iterate_prb<false><<<grid, LRT_BLOCK, 0, st>>>(D->sc, rp, D->q[cur], D->q[cur ^ 1], D->dl[cur], D->dl[cur ^ 1], D->counters, m, nullptr, nullptr, film, sample_out, lane_begin);
+            else if (O.integrator == LRT_INTEGRATOR_PATH)
+                k_iterate<LRT_INTEGRATOR_PATH><<<grid, LRT_BLOCK, 0, st>>>(D->sc, rp, D->q[cur], D->q[cur ^ 1], D->counters, m, film, sample_out, lane_begin);
+            else
+                k_iterate<LRT_INTEGRATOR_VOLPATH><<<grid, LRT_BLOCK, 0, st>>>(D->sc, rp, D->q[cur], D->q[cur ^ 1], D->counters, m, film, sample_out, lane_begin);
+        });
+    }
+    finish_stats(D, log, e_begin, e_end, n_lanes, stats);
 }
 
 void device_render(DeviceScene *D, const lrt_scene_desc &d, const lrt_render_opts *opts, float *film_raw, float *image, lrt_render_stats &stats) {
@@ -475,7 +511,57 @@ void device_trace(DeviceScene *D, const lrt_rays_soa *rays, const lrt_hits_soa *
 } // namespace lrt
 
 namespace lrt {
-void device_render_backward(DeviceScene *, const lrt_scene_desc &, const lrt_render_opts *, const float *, lrt_param_grads *) {
-    throw std::runtime_error("render_backward: not supported yet");
+
+// RBIntegrator.render_backward (common.py:625-783): weight film (non-box filters) -> per chunk: primal pass into L_buf,
+// adjoint replay accumulating d(sum(image * grad_image)) / d(sigma_t, albedo, g) into 7 doubles.
+void device_render_backward(DeviceScene *D, const lrt_scene_desc &d, const lrt_render_opts *opts, const float *grad_image, lrt_param_grads *out, lrt_render_stats &stats) {
+    HIP_CHECK(hipSetDevice(D->device));
+    ResolvedOpts O = resolve(d, opts);
+    O.integrator = LRT_INTEGRATOR_PRBVOLPATH;
+    hipStream_t st = D->stream;
+    const DFilm &F = D->sc.film;
+    const size_t np = (size_t) F.width * F.height, T = F.has_alpha ? 4 : 3;
+    if ((uint64_t) np * O.spp > 0xffffffffull) throw std::runtime_error("more than 2^32 samples per render");
+    ensure_pixel_list(D, O);
+    const uint64_t n_lanes = (uint64_t) D->n_owned_pixels * O.spp;
+    const uint32_t *pixel_list = O.tile_count > 1 ? D->pixel_list : nullptr;
+    DRenderParams rp = make_params(d, O, n_lanes);
+    const uint32_t chunk = (uint32_t) std::min<uint64_t>(std::max<uint64_t>(n_lanes, 1), 1u << 23);
+    ensure_workspace(D, chunk); ensure_prb_workspace(D, chunk);
+    const float *g_img = grad_image;
+    if (!(opts && opts->output_on_device)) {
+        if (D->grad_floats < np * T) { HIP_CHECK(hipMalloc((void **) &D->grad_image, np * T * 4)); D->track(D->grad_image); D->grad_floats = np * T; }
+        HIP_CHECK(hipMemcpyAsync(D->grad_image, grad_image, np * T * 4, hipMemcpyHostToDevice, st));
+        g_img = D->grad_image;
+    }
+    if (F.rfilter != LRT_RFILTER_BOX) {
+        if (D->wfilm_floats < np) { HIP_CHECK(hipMalloc((void **) &D->wfilm, np * 4)); D->track(D->wfilm); D->wfilm_floats = np; }
+        HIP_CHECK(hipMemsetAsync(D->wfilm, 0, np * 4, st));
+        uint64_t all = (uint64_t) np * O.spp;             // every lane of the image, also those of other ranks' tiles
+        k_weight_film<<<(uint32_t) ((all + LRT_BLOCK - 1) / LRT_BLOCK), LRT_BLOCK, 0, st>>>(D->sc, rp, D->wfilm, all);
+    }
+    HIP_CHECK(hipMemsetAsync(D->d_grads, 0, 7 * sizeof(double), st));
+    HIP_CHECK(hipMemsetAsync(D->counters, 0, sizeof(DCounters), st));
+    LaunchLog log;
+    hipEvent_t e_begin = get_event(D, log.ev++), e_end = get_event(D, log.ev++);
+    HIP_CHECK(hipEventRecord(e_begin, st));
+    for (uint64_t base = 0; base < n_lanes; base += chunk) {
+        uint32_t n = (uint32_t) std::min<uint64_t>(chunk, n_lanes - base);
+        uint32_t grid0 = (n + LRT_BLOCK - 1) / LRT_BLOCK;
+        k_raygen_prb<false><<<grid0, LRT_BLOCK, 0, st>>>(D->sc, rp, D->q[0], D->dl[0], pixel_list, base, n, nullptr, nullptr, nullptr);
+        drain_chunk(D, n, log, true, [&](int cur, uint32_t m) {
+            k_iterate_prb<false><<<(m + LRT_BLOCK - 1) / LRT_BLOCK, LRT_BLOCK, 0, st>>>(D->sc, rp, D->q[cur], D->q[cur ^ 1], D->dl[cur], D->dl[cur ^ 1], D->counters, m, D->L_buf, nullptr, nullptr, nullptr, 0);
+        });
+        k_raygen_prb<true><<<grid0, LRT_BLOCK, 0, st>>>(D->sc, rp, D->q[0], D->dl[0], pixel_list, base, n, D->L_buf, g_img, D->wfilm);
+        drain_chunk(D, n, log, true, [&](int cur, uint32_t m) {
+            k_iterate_prb<true><<<(m + LRT_BLOCK - 1) / LRT_BLOCK, LRT_BLOCK, 0, st>>>(D->sc, rp, D->q[cur], D->q[cur ^ 1], D->dl[cur], D->dl[cur ^ 1], D->counters, m, nullptr, D->d_grads, nullptr, nullptr, 0);
+        });
+    }
+    finish_stats(D, log, e_begin, e_end, n_lanes, stats);
+    double h[7];
+    HIP_CHECK(hipMemcpy(h, D->d_grads, sizeof(h), hipMemcpyDeviceToHost));
+    for (int k = 0; k < 3; ++k) { out->d_sigma_t[k] = (float) h[k]; out->d_albedo[k] = (float) h[3 + k]; }
+    out->d_g = (float) h[6];
 }
-}
+
+} // namespace lrt

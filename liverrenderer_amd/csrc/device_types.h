@@ -28,6 +28,7 @@ struct DTexture {
 struct DMedium {
     float sigma_t[3]; float albedo[3];   // sigma_t already multiplied by scale
     int32_t has_spectral_extinction, sample_emitters, phase; float g;
+    float scale; float pad;              // sigma_t = property * scale (needed by the PRB adjoint)
 };
 
 struct DEmitter {

@@ -762,6 +762,228 @@ static void path_sample(Ctx &C, Ray ray, V3 *out, bool *out_valid) {
     *out = valid_ray ? result : V3(0.f); *out_valid = valid_ray;
 }
 
+/* --------------------------------------------------- PRB (prbvolpath.py) */
+/* Gradient accumulators of one lane: d/d sigma_t[3] (w.r.t. the `sigma_t` property, i.e. before `scale`),
+   d/d albedo[3], d/d g of medium 0..: the reference differentiates whatever parameters have gradients
+   enabled; the oracle differentiates every medium's parameters into ONE set (scenes in scope have one medium). */
+struct Grads { double sigma_t[3] = { 0, 0, 0 }, albedo[3] = { 0, 0, 0 }, g = 0;
+               void add(const Grads &o) { for (int i = 0; i < 3; ++i) { sigma_t[i] += o.sigma_t[i]; albedo[i] += o.albedo[i]; } g += o.g; } };
+
+/* d ln(hg)/dg: hg = (1-g^2) / (4 pi (1+g^2+2 g c)^(3/2)) (src/phase/hg.cpp:64-68) */
+static inline float hg_dlog_dg(float g, float c) {
+    float temp = 1.f + sqr(g) + 2.f * g * c;
+    return -2.f * g / (1.f - sqr(g)) - 1.5f * (2.f * g + 2.f * c) / temp;
+}
+
+/* src/python/python/ad/integrators/prbvolpath.py:354-444.  adjoint: backpropagates delta_L * adj_emitted
+   through the per-segment transmittance (homogeneous media: analytic transmittance, :403-407). */
+static V3 prb_sample_emitter(Ctx &C, V3 ref_p, V3 ref_n, const SI *ref_si, int medium, uint32_t channel, DirSample *ds_out,
+                             bool adjoint, V3 delta_L, V3 adj_emitted, Grads *G) {
+    const Scene &S = C.S;
+    float sx = C.next(), sy = C.next();
+    DirSample ds; V3 emitter_val = sample_emitter_direction(S, ref_p, sx, sy, &ds);
+    *ds_out = ds;
+    bool active = ds.pdf != 0.f;
+    if (!active) { emitter_val = V3(0.f); medium = -1; }
+    if (ref_si && is_medium_transition(S.shapes[ref_si->shape])) medium = target_medium(S.shapes[ref_si->shape], ds.d, ref_si->n);
+    Ray ray = spawn_ray_to(ref_p, ref_n, ds.p);
+    float max_dist = ray.maxt, total_dist = 0.f;
+    SI si; memset((void *) &si, 0, sizeof(si));
+    bool needs_intersection = true;
+    V3 transmittance(1.f);
+    while (active) {
+        float remaining_dist = max_dist - total_dist;
+        ray.maxt = remaining_dist;
+        active = active && remaining_dist > 0.f;
+        needs_intersection = needs_intersection && active;
+        if (needs_intersection) { C.n_shadow++; C.n_shadow_needed++; Hit h = S.intersect(ray, false, false); si = S.compute_si(ray, h); }
+        needs_intersection = false;
+        bool active_medium = active && medium >= 0, active_surface = active && !active_medium;
+        V3 tr_multiplier(1.f);
+        float seg_t = 0.f; bool escaped_medium = false;
+        if (active_medium) {
+            (void) C.next();                         /* sample_interaction draw, overwritten below (:399-407) */
+            const lrt_medium_desc &M = S.media[medium];
+            V3 sigmat = V3(M.sigma_t[0], M.sigma_t[1], M.sigma_t[2]) * M.scale;
+            float t = fminf(remaining_dist, si.t);   /* mei.t = min(remaining, si.t); tr = exp(-(min(mei.t, si.t) - mint) sigma) */
+            seg_t = fminf(t, si.t) - 0.f;
+            tr_multiplier = V3(m_exp(-seg_t * sigmat.x), m_exp(-seg_t * sigmat.y), m_exp(-seg_t * sigmat.z));
+            escaped_medium = true; active_medium = false;
+        }
+        active_surface = (active_surface || escaped_medium) && si.valid && !active_medium;
+        if (active_surface) tr_multiplier *= bsdf_null_transmission(S, S.shapes[si.shape].bsdf);
+        if (adjoint && escaped_medium && active_surface) {           /* :425-427, active_adj = (surface | medium) & tr > 0 */
+            const lrt_medium_desc &M = S.media[medium];
+            float c[3] = { tr_multiplier.x, tr_multiplier.y, tr_multiplier.z }, dl[3] = { delta_L.x, delta_L.y, delta_L.z }, ae[3] = { adj_emitted.x, adj_emitted.y, adj_emitted.z };
+            for (int k = 0; k < 3; ++k) if (c[k] > 0.f) G->sigma_t[k] += (double) (dl[k] * ae[k] * (-seg_t) * M.scale);
+        }
+        transmittance *= tr_multiplier;
+        if (active_surface) ray = spawn_ray(si.p, si.n, ray.d);
+        ray.maxt = remaining_dist;
+        needs_intersection = needs_intersection || active_surface;
+        active = active && (active_medium || active_surface) && any_nonzero(transmittance);
+        if (active) total_dist += active_medium ? kInf : si.t;
+        if (active_surface && is_medium_transition(S.shapes[si.shape])) medium = target_medium(S.shapes[si.shape], ray.d, si.n);
+    }
+    return emitter_val * transmittance;
+}
+
+/* src/python/python/ad/integrators/prbvolpath.py:96-351.  adjoint == false: primal pass (returns L);
+   adjoint == true: replay with L_in (the primal result) and delta_L, accumulating parameter gradients. */
+static void prb_sample(Ctx &C, Ray ray, bool adjoint, V3 delta_L, V3 L_in, V3 *L_out, bool *valid_out, Grads *G) {
+    const Scene &S = C.S;
+    uint32_t depth = 0;
+    V3 L = adjoint ? L_in : V3(0.f), throughput(1.f);
+    float eta = 1.f;
+    bool active = true, needs_intersection = true, valid_ray = false, specular_chain = true;
+    SI si; memset((void *) &si, 0, sizeof(si));
+    V3 last_scatter_p(0.f); float last_scatter_direction_pdf = 1.f;
+    int medium = -1;                                  /* :127-128 "TODO: support sensors inside media" */
+    uint32_t channel = std::min((uint32_t) (3.f * C.next()), 2u);
+    const uint32_t max_depth = (uint32_t) C.max_depth;
+    while (active) {
+        C.n_iter++;
+        active = any_nonzero(throughput);
+        float q = fminf(max3(throughput) * sqr(eta), 0.99f);
+        bool perform_rr = depth > (uint32_t) C.rr_depth;
+        if (active) { float u = C.next(); active = (u < q) || !perform_rr; }
+        if (perform_rr) throughput *= rcp(q);
+        bool active_medium = active && medium >= 0, active_surface = active && !active_medium;
+        bool escaped_medium = false, act_medium_scatter = false;
+        MI mei; mei.t = kInf; mei.wi = -ray.d; mei.p = V3(0.f); mei.medium = medium;
+        V3 weight(1.f);
+        float seg_t = 0.f; bool in_medium_segment = false;
+        if (active_medium) {
+            mei = medium_sample_interaction(S, medium, ray, C.next(), channel);
+            if (mei.valid()) ray.maxt = mei.t;
+            if (needs_intersection) { Hit h = S.intersect(ray, false, false); si = S.compute_si(ray, h); }
+            needs_intersection = false;
+            if (si.t < mei.t) mei.t = kInf;
+            seg_t = fminf(mei.t, si.t) - mei.mint;                                  /* medium.cpp:92-104 */
+            V3 tr(m_exp(-seg_t * mei.combined.x), m_exp(-seg_t * mei.combined.y), m_exp(-seg_t * mei.combined.z));
+            V3 pdf = (si.t < mei.t) ? tr : tr * mei.combined;
+            float tr_pdf = idx3(pdf, channel);
+            weight = (tr_pdf > 0.f) ? tr / tr_pdf : V3(0.f);
+            escaped_medium = !mei.valid();
+            active_medium = mei.valid();
+            in_medium_segment = true;
+            if (active_medium) { act_medium_scatter = true; depth += 1; last_scatter_p = mei.p; }
+        }
+        active = active && depth < max_depth;
+        act_medium_scatter = act_medium_scatter && active;
+        if (act_medium_scatter) weight *= mei.sigma_s;
+        throughput *= weight;
+        if (adjoint && in_medium_segment) {                                         /* :199-204 */
+            const lrt_medium_desc &M = S.media[medium];
+            float w[3] = { weight.x, weight.y, weight.z }, l[3] = { L.x, L.y, L.z }, dl[3] = { delta_L.x, delta_L.y, delta_L.z };
+            for (int k = 0; k < 3; ++k) {
+                float Lo = l[k] / fmaxf(1e-8f, w[k]);
+                /* weight_k = exp(-t sigma_k) / pdf [* sigma_k a_k]:  d/dsigma_k = w (-t [+ 1/sigma_k]),  d/da_k = w / a_k */
+                float st = M.sigma_t[k] * M.scale;
+                float dws = w[k] * (-seg_t) + (act_medium_scatter ? w[k] / st : 0.f);
+                if (!(seg_t < kInf)) dws = 0.f;                                     /* exp(-inf) = 0: no dependence */
+                G->sigma_t[k] += (double) (dl[k] * Lo * dws * M.scale);
+                if (act_medium_scatter) G->albedo[k] += (double) (dl[k] * Lo * (w[k] / M.albedo[k]));
+            }
+        }
+        /* ---- surface interactions */
+        active_surface = active_surface || escaped_medium;
+        bool intersect = active_surface && needs_intersection;
+        if (intersect) { Hit h = S.intersect(ray, false, false); si = S.compute_si(ray, h); }
+        if (C.hide_emitters && intersect && depth == 0 && si.valid && S.shapes[si.shape].emitter >= 0) {
+            Ray r2 = spawn_ray(si.p, si.n, ray.d);
+            bool a = true; Hit h; h.prim = 0xffffffffu; h.t = kInf;
+            while (a) {
+                h = S.intersect(r2, false, false);
+                a = h.valid() && S.shapes[S.face_shape[h.prim]].emitter >= 0;
+                if (a) { SI s2 = S.compute_si(r2, h); r2 = spawn_ray(s2.p, s2.n, r2.d); }
+            }
+            si = S.compute_si(r2, h);
+        }
+        if (active_surface) {
+            bool count_direct = (depth == 0) || specular_chain;
+            int emitter = si_emitter(S, si);
+            bool active_e = emitter >= 0 && !(depth == 0 && C.hide_emitters);
+            if (active_e) {
+                float emitter_pdf = pdf_emitter_direction(S, last_scatter_p, si, emitter);
+                V3 emitted = emitter_eval(S, emitter, si);
+                V3 contrib = count_direct ? throughput * emitted : throughput * mis_weight(last_scatter_direction_pdf, emitter_pdf) * emitted;
+                L = adjoint ? L - contrib : L + contrib;
+            }
+        }
+        active_surface = active_surface && si.valid;
+        /* ---- emitter sampling (:267-297) */
+        int b = active_surface ? S.shapes[si.shape].bsdf : -1;
+        bool active_e_surface = active_surface && (bsdf_flags(S, b) & F_SMOOTH) && (depth + 1 < max_depth);
+        bool sample_emitters = act_medium_scatter ? (S.media[medium].sample_emitters != 0) : false;
+        if (act_medium_scatter) specular_chain = !sample_emitters;
+        bool active_e_medium = act_medium_scatter && sample_emitters;
+        if (active_e_surface || active_e_medium) {
+            PCG32 nee_rng = C.rng;                    /* sampler.clone(): the adjoint call replays the same numbers */
+            DirSample ds;
+            V3 rp = active_e_medium ? mei.p : si.p, rn = active_e_medium ? V3(0.f) : si.n;
+            V3 emitted = prb_sample_emitter(C, rp, rn, active_e_surface ? &si : nullptr, medium, channel, &ds, false, V3(0.f), V3(0.f), nullptr);
+            V3 nee_weight; float nee_pdf;
+            if (active_e_surface) { V3 wo = si.sh.to_local(ds.d); nee_weight = bsdf_eval(S, b, si, wo); nee_pdf = bsdf_pdf(S, b, si, wo); }
+            else { float pv = phase_eval(S.media[medium], mei.wi, ds.d); nee_weight = V3(pv); nee_pdf = pv; }
+            V3 contrib = throughput * nee_weight * mis_weight(ds.pdf, ds.delta ? 0.f : nee_pdf) * emitted;
+            L = adjoint ? L - contrib : L + contrib;
+            if (adjoint) {
+                PCG32 saved = C.rng; uint64_t ns = C.n_shadow, nn = C.n_shadow_needed;
+                C.rng = nee_rng;
+                DirSample ds2;
+                prb_sample_emitter(C, rp, rn, active_e_surface ? &si : nullptr, medium, channel, &ds2, true, delta_L, contrib, G);
+                C.rng = saved; C.n_shadow = ns; C.n_shadow_needed = nn;
+                if (active_e_medium && S.media[medium].phase == LRT_PHASE_HG) {    /* backward(dL * contrib) through phase_val */
+                    float dlg = hg_dlog_dg(S.media[medium].g, dot(ds.d, mei.wi));
+                    G->g += (double) ((delta_L.x * contrib.x + delta_L.y * contrib.y + delta_L.z * contrib.z) * dlg);
+                }
+            }
+        }
+        /* ---- phase function sampling (:299-317) */
+        if (act_medium_scatter) {
+            valid_ray = true;
+            const lrt_medium_desc &M = S.media[medium];
+            (void) C.next();
+            float s2x = C.next(), s2y = C.next();
+            V3 wo; float phase_pdf; phase_sample(M, mei.wi, s2x, s2y, &wo, &phase_pdf);
+            act_medium_scatter = phase_pdf > 0.f;
+            if (act_medium_scatter) {
+                if (adjoint && M.phase == LRT_PHASE_HG) {
+                    float pe = phase_eval(M, mei.wi, wo);
+                    float dlg = hg_dlog_dg(M.g, dot(wo, mei.wi));
+                    float l[3] = { L.x, L.y, L.z }, dl[3] = { delta_L.x, delta_L.y, delta_L.z };
+                    for (int k = 0; k < 3; ++k) G->g += (double) (dl[k] * (pe * (l[k] / fmaxf(1e-8f, pe))) * dlg);
+                }
+                ray = spawn_ray(mei.p, V3(0.f), wo);
+                needs_intersection = true;
+                last_scatter_direction_pdf = phase_pdf;
+            }
+        }
+        /* ---- BSDF sampling (:321-349) */
+        if (active_surface) {
+            const lrt_shape_desc &sd = S.shapes[si.shape];
+            float s1 = C.next(), s2x = C.next(), s2y = C.next();
+            BSDFSample bs; V3 bsdf_weight;
+            bsdf_sample(S, b, si, s1, s2x, s2y, &bs, &bsdf_weight);
+            active_surface = bs.pdf > 0.f;
+            if (active_surface) {
+                throughput *= bsdf_weight;
+                eta *= bs.eta;
+                ray = spawn_ray(si.p, si.n, si.sh.to_world(bs.wo));
+                needs_intersection = true;
+                bool non_null = !(bs.type & F_NULL);
+                if (non_null) { depth += 1; last_scatter_p = si.p; last_scatter_direction_pdf = bs.pdf; valid_ray = true; }
+                specular_chain = specular_chain || (non_null && (bs.type & F_DELTA));
+                specular_chain = specular_chain && !(bs.type & F_SMOOTH);
+                if (is_medium_transition(sd)) medium = target_medium(sd, ray.d, si.n);
+            }
+        }
+        active = active && (active_surface || active_medium);
+    }
+    *L_out = L; *valid_out = valid_ray;
+}
+
 /* ------------------------------------------------------------------ film */
 struct Opts { int integrator, max_depth, rr_depth; bool hide_emitters; uint32_t spp, seed; };
 
@@ -795,6 +1017,7 @@ static SampleOut render_lane(const Scene &S, const Opts &O, uint64_t lane, orc_s
     Ray ray = sample_ray(S, ax, ay);
     V3 L; bool valid;
     if (O.integrator == LRT_INTEGRATOR_PATH) path_sample(C, ray, &L, &valid);
+    else if (O.integrator == LRT_INTEGRATOR_PRBVOLPATH) prb_sample(C, ray, false, V3(0.f), V3(0.f), &L, &valid, nullptr);
     else volpath_sample(C, ray, S.d.sensor.medium, &L, &valid);
     if (st) { st->n_iter += C.n_iter; st->n_shadow += C.n_shadow; st->n_shadow_needed += C.n_shadow_needed; st->n_samples += 1; }
     SampleOut o; o.r = L.x; o.g = L.y; o.b = L.z; o.a = valid ? 1.f : 0.f;
@@ -1017,4 +1240,75 @@ extern "C" void orc_envmap_eval(orc_scene *s, const float d[3], float rgb[3]) {
 extern "C" float orc_rfilter_eval(orc_scene *s, float x) { return s->s.rfilter_eval(x); }
 extern "C" void orc_sample_ray(orc_scene *s, float px, float py, float o[3], float d[3], float *maxt) {
     Ray r = sample_ray(s->s, px, py); o[0] = r.o.x; o[1] = r.o.y; o[2] = r.o.z; d[0] = r.d.x; d[1] = r.d.y; d[2] = r.d.z; *maxt = r.maxt;
+}
+
+/* RBIntegrator.render_backward (src/python/python/ad/integrators/common.py:625-783):
+   (0) delta_L = d(sum(image * grad_image))/dL per sample through splat + develop (:730-746),
+   (1) primal pass, (2) adjoint replay with the same sampler state. */
+extern "C" int orc_render_backward(orc_scene *s, const lrt_render_opts *opts, int n_threads, const float *grad_image, lrt_param_grads *out) {
+    const Scene &S = s->s; Opts O = resolve_opts(S, opts);
+    const lrt_film_desc &F = S.d.film;
+    const int T = F.has_alpha ? 4 : 3, W = F.crop_width, H = F.crop_height;
+    const size_t np = (size_t) W * H; const uint64_t N = (uint64_t) np * O.spp;
+    if (N > 0xffffffffull) { g_err = "orc_render_backward: more than 2^32 lanes"; return 1; }
+    const bool box = F.rfilter == LRT_RFILTER_BOX;
+    int nt = hw_threads(n_threads);
+    auto lane_setup = [&](uint64_t lane, Ctx &C, float *spx, float *spy, Ray *ray) {
+        C.max_depth = O.max_depth; C.rr_depth = O.rr_depth; C.hide_emitters = O.hide_emitters;
+        C.rng = lane_rng(S.d.sampler_seed, O.seed, (uint32_t) lane);
+        uint32_t idx = (uint32_t) (lane / O.spp), py = idx / (uint32_t) W, px = idx - py * (uint32_t) W;
+        float posx = (float) ((int) px + F.crop_offset_x), posy = (float) ((int) py + F.crop_offset_y);
+        float jx = C.next(), jy = C.next();
+        *spx = posx + jx; *spy = posy + jy;
+        *ray = sample_ray(S, fmaf(*spx, 1.f / (float) W, -(float) F.crop_offset_x / (float) W), fmaf(*spy, 1.f / (float) H, -(float) F.crop_offset_y / (float) H));
+    };
+    /* weight film (sum of filter weights per pixel); box filter: exactly spp */
+    std::vector<float> wfilm(np, box ? (float) O.spp : 0.f);
+    const int fn = (int) ceilf(S.rf_radius - .5f), fcount = 2 * fn + 1;
+    if (!box) {
+        for (uint64_t lane = 0; lane < N; ++lane) {
+            Ctx C(S); float spx, spy; Ray ray; lane_setup(lane, C, &spx, &spy, &ray);
+            int pix = (int) floorf(spx) - fn, piy = (int) floorf(spy) - fn;
+            float relx = (float) pix + .5f - spx, rely = (float) piy + .5f - spy;
+            for (int ys = 0; ys < fcount; ++ys) for (int xs = 0; xs < fcount; ++xs) {
+                int x = pix - F.crop_offset_x + xs, y = piy - F.crop_offset_y + ys;
+                if (x < 0 || y < 0 || x >= W || y >= H) continue;
+                wfilm[(size_t) y * W + x] += S.rfilter_eval(rely + (float) ys) * S.rfilter_eval(relx + (float) xs);
+            }
+        }
+    }
+    std::vector<Grads> G(nt);
+    parallel_for(N, nt, [&](uint64_t b, uint64_t e, int t) {
+        for (uint64_t lane = b; lane < e; ++lane) {
+            Ctx C(S); float spx, spy; Ray ray; lane_setup(lane, C, &spx, &spy, &ray);
+            V3 dL(0.f);
+            if (box) {
+                size_t p = (size_t) (lane / O.spp);
+                float w = wfilm[p]; if (w == 0.f) w = 1.f;
+                dL = V3(grad_image[p * T] / w, grad_image[p * T + 1] / w, grad_image[p * T + 2] / w);
+            } else {
+                int pix = (int) floorf(spx) - fn, piy = (int) floorf(spy) - fn;
+                float relx = (float) pix + .5f - spx, rely = (float) piy + .5f - spy;
+                for (int ys = 0; ys < fcount; ++ys) for (int xs = 0; xs < fcount; ++xs) {
+                    int x = pix - F.crop_offset_x + xs, y = piy - F.crop_offset_y + ys;
+                    if (x < 0 || y < 0 || x >= W || y >= H) continue;
+                    size_t p = (size_t) y * W + x;
+                    float w = S.rfilter_eval(rely + (float) ys) * S.rfilter_eval(relx + (float) xs), wp = wfilm[p]; if (wp == 0.f) wp = 1.f;
+                    float f = w / wp;
+                    dL = dL + V3(grad_image[p * T] * f, grad_image[p * T + 1] * f, grad_image[p * T + 2] * f);
+                }
+            }
+            PCG32 start = C.rng;
+            V3 L; bool valid;
+            prb_sample(C, ray, false, V3(0.f), V3(0.f), &L, &valid, nullptr);
+            C.rng = start; C.n_iter = 0;
+            V3 L2; Grads g;
+            prb_sample(C, ray, true, dL, L, &L2, &valid, &g);
+            G[t].add(g);
+        }
+    });
+    Grads tot; for (auto &g : G) tot.add(g);
+    for (int k = 0; k < 3; ++k) { out->d_sigma_t[k] = (float) tot.sigma_t[k]; out->d_albedo[k] = (float) tot.albedo[k]; }
+    out->d_g = (float) tot.g;
+    return 0;
 }

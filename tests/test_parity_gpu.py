@@ -279,3 +279,45 @@ def test_error_reporting(mi, cornell):
         cornell.param_set("nope.sigma_t.value", [1, 1, 1])
     with pytest.raises(RuntimeError, match="2\\^32"):
         cornell.render(spp=70000)
+
+
+# --------------------------------------------------------------------------- PRB
+from test_oracle_pins import prb_scene_xml, PRB_ENV, PRB_AREA
+
+
+@pytest.mark.parametrize("case", ["null+area", "dielectric+env", "tent"])
+def test_prb_primal_lanes_and_gradients(mi, orc, case):
+    """prbvolpath primal lanes bit-exact; adjoint gradients equal to the oracle's up to summation order
+    (float partial sums per workgroup vs. double per lane: 2e-4 relative to the gradient's scale)."""
+    if case == "null+area": xml = prb_scene_xml("null", PRB_AREA, res=16)
+    elif case == "dielectric+env": xml = prb_scene_xml("dielectric", PRB_ENV, res=16)
+    else: xml = prb_scene_xml("null", PRB_AREA, rf="tent", res=16)
+    sc = mi.load_string(xml); o = orc.OrcScene(sc)
+    spp = 64
+    assert_lanes_equal(sc, o, 0, 16 * 16 * spp, spp=spp, integrator="prbvolpath")
+    rng = np.random.default_rng(3)
+    H, W, T = sc.film_shape()
+    grad = rng.random((H, W, T)).astype(np.float32) / (H * W * T)
+    gg = sc.render_backward(grad, spp=spp, seed=2)
+    gc = o.render_backward(grad, spp=spp, seed=2)
+    for k in ("sigma_t", "albedo"):
+        assert np.abs(gg[k] - gc[k]).max() <= 2e-4 * np.abs(gc[k]).max(), (k, gg[k], gc[k])
+    assert abs(gg["g"] - gc["g"]) <= 2e-4 * max(abs(gc["g"]), 1e-6)
+    # sharded adjoint: per-rank gradients add up (the 7-float all-reduce of SURVEY 8e)
+    parts = [sc.render_backward(grad, spp=spp, seed=2, tile_rank=r, tile_count=2) for r in range(2)]
+    for k in ("sigma_t", "albedo"):
+        assert np.abs(parts[0][k] + parts[1][k] - gc[k]).max() <= 2e-4 * np.abs(gc[k]).max()
+
+
+def test_prb_parenchyma_config5_geometry(mi, orc):
+    """BASELINE config C5 geometry (Parenchyma camera + liver mesh, homogeneous reading) at small size."""
+    sc = mi.load_file(PARENCHYMA_XML, integrator="prbvolpath", spp=16, res_width=96, res_height=54, max_depth=65)
+    o = orc.OrcScene(sc)
+    for s_, o_ in ((sc, o),):
+        s_.param_set("parenchymaMedium.sigma_t.value", [0.05, 0.08, 0.11]); o_.param_set("parenchymaMedium.sigma_t.value", [0.05, 0.08, 0.11])
+    H, W, T = sc.film_shape()
+    grad = np.full((H, W, T), 1.0 / (H * W * T), np.float32)
+    gg = sc.render_backward(grad, seed=7); gc = o.render_backward(grad, seed=7)
+    for k in ("sigma_t", "albedo"):
+        assert np.abs(gg[k] - gc[k]).max() <= 5e-4 * np.abs(gc[k]).max(), (k, gg[k], gc[k])
+    assert np.abs(gc["albedo"]).max() > 0
