@@ -7,7 +7,7 @@
 namespace lrt {
 
 namespace {
-const int kMaxDepth = 30;          // the traversal stack in LDS holds 32 entries
+const int kMaxDepth = 22;          // traversal stacks hold 32 (global path) / 24 (LDS path) entries
 const int kLeafSize = 4;
 const int kBins = 16;
 

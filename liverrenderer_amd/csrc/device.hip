@@ -41,6 +41,7 @@ struct DeviceScene {
     uint32_t *pixel_list = nullptr; uint32_t pixel_list_rank = 0xffffffffu, pixel_list_count = 0, n_owned_pixels = 0;
     std::vector<hipEvent_t> ev_pool;
     std::vector<DMedium> h_media; DMedium *d_media = nullptr;
+    DLdsInfo lds{}; bool use_lds = false; int n_cus = 256;
 
     template <typename T> T *track(T *p) { allocs.push_back((void *) p); return p; }
     ~DeviceScene() {
@@ -172,6 +173,33 @@ DeviceScene *device_scene_create(const lrt_scene_desc &d, int device) {
     sc.tris = (const float4 *) D->track(dev_upload(bvh.tris.data(), bvh.tris.size(), st));
     sc.root_is_leaf = bvh.root_is_leaf; sc.root_leaf_first = bvh.root_first; sc.root_leaf_count = bvh.root_count;
     sc.n_faces = d.n_faces; sc.n_emitters = d.n_emitters;
+    // ---- LDS image of the acceleration structure (persistent kernel): used when it fits next to the traversal stacks
+    {
+        hipDeviceProp_t prop; HIP_CHECK(hipGetDeviceProperties(&prop, device)); D->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        const size_t n_nodes = bvh.nodes.size() / 16, n_slots = bvh.tris.size() / 12, n_verts = d.n_vertices;
+        const size_t nodes_b = n_nodes * 64, verts_b = (n_verts * 16 + 15) & ~size_t(15), tris_b = (n_slots * 8 + 15) & ~size_t(15);
+        const size_t stack_b = (size_t) 2 * LRT_LDS_STACK * LRT_LDS_BLOCK, total = nodes_b + verts_b + tris_b + stack_b;
+        const size_t lds_limit = std::min<size_t>((size_t) prop.sharedMemPerBlock ? 160 * 1024 : 64 * 1024, 160 * 1024) - 512;
+        if (d.n_faces > 0 && n_verts <= 65535 && n_nodes <= 32767 && bvh.max_depth < LRT_LDS_STACK && total <= lds_limit && !getenv("LRT_NO_LDS_BVH")) {
+            std::vector<unsigned char> blob(nodes_b + verts_b + tris_b, 0);
+            memcpy(blob.data(), bvh.nodes.data(), nodes_b);
+            float *v = reinterpret_cast<float *>(blob.data() + nodes_b);
+            for (size_t i = 0; i < n_verts; ++i) { v[4 * i] = d.positions[3 * i]; v[4 * i + 1] = d.positions[3 * i + 1]; v[4 * i + 2] = d.positions[3 * i + 2]; v[4 * i + 3] = 0.f; }
+            uint16_t *t = reinterpret_cast<uint16_t *>(blob.data() + nodes_b + verts_b);
+            std::vector<uint32_t> slot_prim(n_slots);
+            for (size_t sl = 0; sl < n_slots; ++sl) {
+                uint32_t f; memcpy(&f, &bvh.tris[12 * sl + 3], 4); slot_prim[sl] = f;
+                for (int k = 0; k < 3; ++k) t[4 * sl + k] = (uint16_t) d.faces[3 * (size_t) f + k];
+            }
+            D->lds.blob = (const uint4 *) D->track(dev_upload(blob.data(), blob.size(), st));
+            D->lds.slot_prim = D->track(dev_upload(slot_prim.data(), slot_prim.size(), st));
+            D->lds.blob_bytes = (uint32_t) blob.size(); D->lds.nodes_off = 0; D->lds.verts_off = (uint32_t) nodes_b; D->lds.tris_off = (uint32_t) (nodes_b + verts_b);
+            D->lds.stack_off = (uint32_t) blob.size(); D->lds.total_bytes = (uint32_t) total;
+            HIP_CHECK(hipFuncSetAttribute((const void *) k_iterate_lds<LRT_INTEGRATOR_PATH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) total));
+            HIP_CHECK(hipFuncSetAttribute((const void *) k_iterate_lds<LRT_INTEGRATOR_VOLPATH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) total));
+            D->use_lds = true;
+        }
+    }
     // ---- geometry attributes
     sc.positions = D->track(dev_upload(d.positions, 3 * (size_t) d.n_vertices, st));
     sc.normals = D->track(dev_upload(d.normals, 3 * (size_t) d.n_vertices, st));
@@ -356,7 +384,7 @@ static void drain_chunk(DeviceScene *D, uint32_t n, LaunchLog &log, bool count_i
     hipStream_t st = D->stream;
     int cur = 0;
     while (n > 0) {
-        HIP_CHECK(hipMemsetAsync(&D->counters->n_out, 0, sizeof(uint32_t), st));
+        HIP_CHECK(hipMemsetAsync(&D->counters->n_out, 0, 2 * sizeof(uint32_t), st));      // n_out and the tile ticket
         hipEvent_t a = get_event(D, log.ev++), b = get_event(D, log.ev++);
         HIP_CHECK(hipEventRecord(a, st));
         iterate(cur, n);
@@ -416,7 +444,13 @@ static void run_wavefront(DeviceScene *D, const lrt_scene_desc &d, const Resolve
             uint32_t grid = (m + LRT_BLOCK - 1) / LRT_BLOCK;
             if (prb)
                 k_iterate_prb<false><<<grid, LRT_BLOCK, 0, st>>>(D->sc, rp, D->q[cur], D->q[cur ^ 1], D->dl[cur], D->dl[cur ^ 1], D->counters, m, nullptr, nullptr, film, sample_out, lane_begin);
-            else if (O.integrator == LRT_INTEGRATOR_PATH)
+            else if (D->use_lds) {
+                uint32_t g = std::min<uint32_t>((uint32_t) D->n_cus, (m + LRT_LDS_BLOCK - 1) / LRT_LDS_BLOCK);
+                if (O.integrator == LRT_INTEGRATOR_PATH)
+                    k_iterate_lds<LRT_INTEGRATOR_PATH><<<g, LRT_LDS_BLOCK, D->lds.total_bytes, st>>>(D->sc, rp, D->lds, D->q[cur], D->q[cur ^ 1], D->counters, m, film, sample_out, lane_begin);
+                else
+                    k_iterate_lds<LRT_INTEGRATOR_VOLPATH><<<g, LRT_LDS_BLOCK, D->lds.total_bytes, st>>>(D->sc, rp, D->lds, D->q[cur], D->q[cur ^ 1], D->counters, m, film, sample_out, lane_begin);
+            } else if (O.integrator == LRT_INTEGRATOR_PATH)
                 k_iterate<LRT_INTEGRATOR_PATH><<<grid, LRT_BLOCK, 0, st>>>(D->sc, rp, D->q[cur], D->q[cur ^ 1], D->counters, m, film, sample_out, lane_begin);
             else
                 k_iterate<LRT_INTEGRATOR_VOLPATH><<<grid, LRT_BLOCK, 0, st>>>(D->sc, rp, D->q[cur], D->q[cur ^ 1], D->counters, m, film, sample_out, lane_begin);

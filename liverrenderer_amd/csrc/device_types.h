@@ -119,9 +119,16 @@ struct DPathStreams {
 
 struct DCounters {             // device-resident queue / statistics words
     uint32_t n_in, n_out;
-    uint32_t pad[2];
+    uint32_t tile, pad;        // tile: work-distribution ticket of the persistent kernel
     unsigned long long n_shadow;
     unsigned long long n_iter;
+};
+
+// LDS image of the scene for the persistent traversal kernel: [nodes | verts (float4) | tris (4 x u16)] copied verbatim
+// from `blob`, followed by the per-thread traversal stacks.
+struct DLdsInfo {
+    const uint4 *blob; const uint32_t *slot_prim;
+    uint32_t blob_bytes, nodes_off, verts_off, tris_off, stack_off, total_bytes;
 };
 
 } // namespace lrt

@@ -88,6 +88,97 @@ DEV Hit trace(const DScene &sc, const Ray &r, int *__restrict__ stack /* &lds[th
     return best;
 }
 
+// Ray-query back-ends the integrator loops are templated on.
+struct GlobalTracer {                      // BVH in global memory (any scene size), 32-bit stack entries in LDS
+    const DScene &sc; int *stack;
+    DEV Hit closest(const Ray &r) const { return trace<false>(sc, r, stack); }
+    DEV Hit any(const Ray &r) const { return trace<true>(sc, r, stack); }
+};
+
+// Whole BVH resident in LDS (scenes whose image fits next to the traversal stacks: the liver meshes and the Cornell
+// box do): nodes as in bvh.h, vertices padded to float4, triangle slots as 4 x u16 vertex indices, 16-bit stack
+// entries.  Edge vectors are formed in the kernel with the same float subtractions the host builder uses, so hits
+// are bit-identical to the global-memory path.
+struct LdsScene {
+    const float4 *nodes; const float4 *verts; const uint2 *tris; const uint32_t *slot_prim /* global */;
+    uint32_t n_faces, root_is_leaf, root_first, root_count;
+};
+#define LRT_LDS_STACK 24
+#define LRT_LDS_BLOCK 1024
+
+DEV void test_tri_lds(const LdsScene &L, uint32_t slot, V3 o, V3 d, float maxt, Hit &best) {
+    uint2 ix = L.tris[slot];
+    float4 a = L.verts[ix.x & 0xffffu], b = L.verts[ix.x >> 16], c = L.verts[ix.y & 0xffffu];
+    V3 p0(a.x, a.y, a.z), e1(b.x - a.x, b.y - a.y, b.z - a.z), e2(c.x - a.x, c.y - a.y, c.z - a.z);
+    V3 pvec = cross(d, e2);
+    float inv_det = rcp(dot(e1, pvec));
+    V3 tvec = o - p0;
+    float u = dot(tvec, pvec) * inv_det;
+    if (!(u >= 0.f && u <= 1.f)) return;
+    V3 qvec = cross(tvec, e1);
+    float v = dot(d, qvec) * inv_det;
+    if (!(v >= 0.f && u + v <= 1.f)) return;
+    float t = dot(e2, qvec) * inv_det;
+    if (!(t >= 0.f && t <= maxt)) return;
+    if (t > best.t) return;
+    uint32_t f = L.slot_prim[slot];
+    if (t < best.t || f < best.prim) { best.t = t; best.u = u; best.v = v; best.prim = f; }
+}
+
+template <bool ANY_HIT>
+DEV Hit trace_lds(const LdsScene &L, const Ray &r, uint16_t *__restrict__ stack /* &lds_stack[threadIdx.x] */) {
+    Hit best; best.t = kInf; best.u = best.v = 0.f; best.prim = 0xffffffffu;
+    if (L.n_faces == 0) return best;
+    const V3 o = r.o, d = r.d;
+    if (L.root_is_leaf) {
+        for (uint32_t i = 0; i < L.root_count; ++i) test_tri_lds(L, L.root_first + i, o, d, r.maxt, best);
+        return best;
+    }
+    const float ix = 1.f / d.x, iy = 1.f / d.y, iz = 1.f / d.z;
+    int sp = 0, node = 0;
+    for (;;) {
+        const float4 *nd = L.nodes + 4 * node;
+        float4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3];
+        float limit = fmin_(best.t, r.maxt);
+        float t0, t1, tmin0, tmax0, tmin1, tmax1;
+        t0 = (n0.x - o.x) * ix; t1 = (n0.y - o.x) * ix; tmin0 = fmax_(0.f, fmin_(t0, t1)); tmax0 = fmin_(limit, fmax_(t0, t1));
+        t0 = (n0.z - o.y) * iy; t1 = (n0.w - o.y) * iy; tmin0 = fmax_(tmin0, fmin_(t0, t1)); tmax0 = fmin_(tmax0, fmax_(t0, t1));
+        t0 = (n2.x - o.z) * iz; t1 = (n2.y - o.z) * iz; tmin0 = fmax_(tmin0, fmin_(t0, t1)); tmax0 = fmin_(tmax0, fmax_(t0, t1));
+        t0 = (n1.x - o.x) * ix; t1 = (n1.y - o.x) * ix; tmin1 = fmax_(0.f, fmin_(t0, t1)); tmax1 = fmin_(limit, fmax_(t0, t1));
+        t0 = (n1.z - o.y) * iy; t1 = (n1.w - o.y) * iy; tmin1 = fmax_(tmin1, fmin_(t0, t1)); tmax1 = fmin_(tmax1, fmax_(t0, t1));
+        t0 = (n2.z - o.z) * iz; t1 = (n2.w - o.z) * iz; tmin1 = fmax_(tmin1, fmin_(t0, t1)); tmax1 = fmin_(tmax1, fmax_(t0, t1));
+        bool h0 = tmin0 <= tmax0 * 1.0000005f + 1e-30f, h1 = tmin1 <= tmax1 * 1.0000005f + 1e-30f;
+        int r0 = (int) f2u(n3.x), r1 = (int) f2u(n3.y);
+        int next = 0x7fffffff;
+        if (h0 && h1) {
+            bool swap = tmin1 < tmin0;
+            int nearr = swap ? r1 : r0, farr = swap ? r0 : r1;
+            int nearc = swap ? (int) f2u(n3.w) : (int) f2u(n3.z), farc = swap ? (int) f2u(n3.z) : (int) f2u(n3.w);
+            if (nearr < 0) { uint32_t first = (uint32_t) ~nearr; for (int i = 0; i < nearc; ++i) test_tri_lds(L, first + i, o, d, r.maxt, best); }
+            if (farr < 0) { uint32_t first = (uint32_t) ~farr; for (int i = 0; i < farc; ++i) test_tri_lds(L, first + i, o, d, r.maxt, best); }
+            if (nearr >= 0) { next = nearr; if (farr >= 0) { stack[sp * LRT_LDS_BLOCK] = (uint16_t) farr; ++sp; } }
+            else if (farr >= 0) next = farr;
+        } else if (h0 || h1) {
+            int rr = h0 ? r0 : r1, cc = h0 ? (int) f2u(n3.z) : (int) f2u(n3.w);
+            if (rr < 0) { uint32_t first = (uint32_t) ~rr; for (int i = 0; i < cc; ++i) test_tri_lds(L, first + i, o, d, r.maxt, best); }
+            else next = rr;
+        }
+        if (ANY_HIT && best.prim != 0xffffffffu) return best;
+        if (next == 0x7fffffff) {
+            if (sp == 0) break;
+            --sp; next = stack[sp * LRT_LDS_BLOCK];
+        }
+        node = next;
+    }
+    return best;
+}
+
+struct LdsTracer {
+    const LdsScene &L; uint16_t *stack;
+    DEV Hit closest(const Ray &r) const { return trace_lds<false>(L, r, stack); }
+    DEV Hit any(const Ray &r) const { return trace_lds<true>(L, r, stack); }
+};
+
 // --------------------------------------------------- surface interaction
 // src/render/mesh.cpp:1489-1659 + include/mitsuba/render/interaction.h:290-300,516-536
 DEV SI compute_si(const DScene &sc, const Ray &r, const Hit &h) {

@@ -159,10 +159,45 @@ DEV void finish_path(const DScene &sc, const DRenderParams &rp, float *__restric
     }
 }
 
+// Film accumulation called by EVERY lane of a wave (`finishing` selects the lanes that retire a path).  Box filter:
+// lanes that splat into the same pixel are summed inside the wave first (the wavefront keeps a pixel's samples in
+// neighbouring lanes, so a wave usually holds one or two distinct pixels) and one lane issues the atomics.
+DEV void finish_paths_wave(const DScene &sc, const DRenderParams &rp, float *__restrict__ film, float *__restrict__ sample_out,
+                           uint64_t sample_base, bool finishing, uint32_t lane, V3 L, bool valid) {
+    const DFilm &F = sc.film;
+    if (sample_out || F.rfilter != LRT_RFILTER_BOX) {
+        if (finishing) finish_path(sc, rp, film, sample_out, sample_base, lane, L, valid);
+        return;
+    }
+    if (rp.integrator == LRT_INTEGRATOR_PATH && !valid) L = V3(0.f);
+    uint32_t pixel = 0xffffffffu;
+    if (finishing) { int px, py; lane_to_pixel(sc, rp, lane, &px, &py); pixel = (uint32_t) (py - F.crop_offset_y) * (uint32_t) F.width + (uint32_t) (px - F.crop_offset_x); }
+    float a = valid ? 1.f : 0.f;
+    unsigned long long todo = __ballot(finishing);
+    const uint32_t me = threadIdx.x & 63u;
+    while (todo) {
+        int leader = __ffsll((long long) todo) - 1;
+        uint32_t key = __shfl(pixel, leader);
+        bool mine = finishing && pixel == key;
+        unsigned long long grp = __ballot(mine);
+        float r = mine ? L.x : 0.f, g = mine ? L.y : 0.f, b = mine ? L.z : 0.f, al = mine ? a : 0.f, w = mine ? 1.f : 0.f;
+        for (int off = 32; off > 0; off >>= 1) {
+            r += __shfl_xor(r, off); g += __shfl_xor(g, off); b += __shfl_xor(b, off); al += __shfl_xor(al, off); w += __shfl_xor(w, off);
+        }
+        if ((int) me == leader) {
+            float *p = film + (size_t) key * F.channels;
+            atomicAdd(p + 0, r); atomicAdd(p + 1, g); atomicAdd(p + 2, b);
+            if (F.has_alpha) { atomicAdd(p + 3, al); atomicAdd(p + 4, w); } else atomicAdd(p + 3, w);
+        }
+        todo &= ~grp;
+    }
+}
+
 // ---------------------------------------------------------- volpath NEE
 // src/integrators/volpath.cpp:400-554.  ref_n is zero for medium interactions.
+template <typename TR>
 DEV V3 volpath_sample_emitter(const DScene &sc, PCG32 &rng, V3 ref_p, V3 ref_n, bool ref_is_surface, uint32_t ref_shape, V3 ref_geo_n,
-                              int medium, uint32_t channel, DirSample *ds_out, int *stack, uint32_t &n_shadow) {
+                              int medium, uint32_t channel, DirSample *ds_out, const TR &tr, uint32_t &n_shadow) {
     V3 transmittance(1.f);
     float sx = rng.next(), sy = rng.next();
     DirSample ds; V3 emitter_val = sample_emitter_direction(sc, ref_p, sx, sy, &ds);
@@ -187,7 +222,7 @@ DEV V3 volpath_sample_emitter(const DScene &sc, PCG32 &rng, V3 ref_p, V3 ref_n, 
                 // Exact shortcut: a real collision (sigma_n = 0) kills the sample whether or not a
                 // surface lies in front of it when every surface blocks (no null BSDF): skip the query.
                 bool elide = mei.valid() && !sc.has_null_bsdf;
-                if (!elide) { n_shadow++; Hit h = trace<false>(sc, ray, stack); si = compute_si(sc, ray, h); }
+                if (!elide) { n_shadow++; Hit h = tr.closest(ray); si = compute_si(sc, ray, h); }
                 else { si.valid = false; si.t = kInf; }
             }
             if (si.t < mei.t) mei.t = kInf;
@@ -213,7 +248,7 @@ DEV V3 volpath_sample_emitter(const DScene &sc, PCG32 &rng, V3 ref_p, V3 ref_n, 
             }
         }
         bool intersect = active_surface && needs_intersection;
-        if (intersect) { n_shadow++; Hit h = trace<false>(sc, ray, stack); si = compute_si(sc, ray, h); needs_intersection = false; }
+        if (intersect) { n_shadow++; Hit h = tr.closest(ray); si = compute_si(sc, ray, h); needs_intersection = false; }
         active_surface = active_surface || escaped_medium;
         if (active_surface) total_dist += si.t;
         active_surface = active_surface && si.valid && !active_medium;
@@ -231,7 +266,8 @@ DEV V3 volpath_sample_emitter(const DScene &sc, PCG32 &rng, V3 ref_p, V3 ref_n, 
 
 // One trip of volpath's while_loop (src/integrators/volpath.cpp:170-391).
 // Returns true when the path survives.
-DEV bool volpath_iteration(const DScene &sc, const DRenderParams &rp, PathState &s, PCG32 &rng, int *stack, uint32_t &n_shadow) {
+template <typename TR>
+DEV bool volpath_iteration(const DScene &sc, const DRenderParams &rp, PathState &s, PCG32 &rng, const TR &tr, uint32_t &n_shadow) {
     uint32_t depth = s.flags & PF_DEPTH_MASK;
     int medium = (int) ((s.flags & PF_MEDIUM_MASK) >> PF_MEDIUM_SHIFT) - 1;
     const uint32_t channel = (s.flags >> PF_CHANNEL_SHIFT) & 3u;
@@ -262,7 +298,7 @@ DEV bool volpath_iteration(const DScene &sc, const DRenderParams &rp, PathState 
         const DMedium M = sc.media[medium];
         mei = medium_sample_interaction(M, ray, rng.next(), channel);
         if (mei.valid()) ray.maxt = mei.t;
-        { Hit h = trace<false>(sc, ray, stack); si = compute_si(sc, ray, h); }
+        { Hit h = tr.closest(ray); si = compute_si(sc, ray, h); }
         if (si.t < mei.t) mei.t = kInf;
         if (M.has_spectral_extinction) {
             float t = fmin_(mei.t, si.t) - mei.mint;
@@ -291,7 +327,7 @@ DEV bool volpath_iteration(const DScene &sc, const DRenderParams &rp, PathState 
         specular_chain = !sample_emitters;
         if (sample_emitters) {
             DirSample ds;
-            V3 emitted = volpath_sample_emitter(sc, rng, mei.p, V3(0.f), false, 0, V3(0.f), medium, channel, &ds, stack, n_shadow);
+            V3 emitted = volpath_sample_emitter(sc, rng, mei.p, V3(0.f), false, 0, V3(0.f), medium, channel, &ds, tr, n_shadow);
             float phase_val = phase_eval(M, mei.wi, ds.d);
             V3 c = throughput * phase_val * emitted * mis_weight(ds.pdf, ds.delta ? 0.f : phase_val);
             result = result + c;
@@ -307,7 +343,7 @@ DEV bool volpath_iteration(const DScene &sc, const DRenderParams &rp, PathState 
     // ---- surface interactions
     active_surface = active_surface || escaped_medium;
     bool intersect = active_surface && !escaped_medium;   // medium lanes already hold si
-    if (intersect) { Hit h = trace<false>(sc, ray, stack); si = compute_si(sc, ray, h); }
+    if (intersect) { Hit h = tr.closest(ray); si = compute_si(sc, ray, h); }
     if (active_surface) {
         if (rp.hide_emitters && depth == 0 && intersect) {         // volpath.cpp:304-320, integrator.cpp:96-123
             bool skip = si.valid && sc.shapes[si.shape].emitter >= 0;
@@ -315,7 +351,7 @@ DEV bool volpath_iteration(const DScene &sc, const DRenderParams &rp, PathState 
                 Ray r2 = spawn_ray(si.p, si.n, ray.d);
                 bool a = true; Hit h; h.prim = 0xffffffffu; h.t = kInf; h.u = h.v = 0.f;
                 while (a) {
-                    h = trace<false>(sc, r2, stack);
+                    h = tr.closest(r2);
                     a = h.prim != 0xffffffffu && sc.shapes[sc.face_shape[h.prim]].emitter >= 0;
                     if (a) { SI s2 = compute_si(sc, r2, h); r2 = spawn_ray(s2.p, s2.n, r2.d); }
                 }
@@ -341,7 +377,7 @@ DEV bool volpath_iteration(const DScene &sc, const DRenderParams &rp, PathState 
         bool active_e = (flags & F_SMOOTH) && (depth + 1 < max_depth);
         if (active_e) {
             DirSample ds;
-            V3 emitted = volpath_sample_emitter(sc, rng, si.p, si.n, true, si.shape, si.n, medium, channel, &ds, stack, n_shadow);
+            V3 emitted = volpath_sample_emitter(sc, rng, si.p, si.n, true, si.shape, si.n, medium, channel, &ds, tr, n_shadow);
             V3 wo = si.sh.to_local(ds.d);
             V3 bsdf_val = bsdf_eval(sc, b, si, wo);
             float bpdf = bsdf_pdf(sc, b, si, wo);
@@ -367,7 +403,8 @@ DEV bool volpath_iteration(const DScene &sc, const DRenderParams &rp, PathState 
 // One trip of path's while_loop (src/integrators/path.cpp:194-338); the
 // ray_intersect_preliminary of the previous trip (:332-337, or :164-169 for the
 // first one) is the trace at the top.
-DEV bool path_iteration(const DScene &sc, const DRenderParams &rp, PathState &s, PCG32 &rng, int *stack, uint32_t &n_shadow) {
+template <typename TR>
+DEV bool path_iteration(const DScene &sc, const DRenderParams &rp, PathState &s, PCG32 &rng, const TR &tr, uint32_t &n_shadow) {
     uint32_t depth = s.flags & PF_DEPTH_MASK;
     bool prev_bsdf_delta = (s.flags & PF_SPECULAR) != 0, valid_ray = (s.flags & PF_VALID) != 0;
     const uint32_t max_depth = (uint32_t) rp.max_depth;
@@ -379,7 +416,7 @@ DEV bool path_iteration(const DScene &sc, const DRenderParams &rp, PathState &s,
         s.flags = (depth & PF_DEPTH_MASK) | (prev_bsdf_delta ? PF_SPECULAR : 0u) | (valid_ray ? PF_VALID : 0u);
     };
     if (max_depth == 0) { commit(); return false; }
-    Hit pi = trace<false>(sc, ray, stack);
+    Hit pi = tr.closest(ray);
     if (rp.hide_emitters && depth == 0) {                          // path.cpp:178-192
         bool skip = pi.prim != 0xffffffffu && sc.shapes[sc.face_shape[pi.prim]].emitter >= 0;
         if (skip) {
@@ -387,7 +424,7 @@ DEV bool path_iteration(const DScene &sc, const DRenderParams &rp, PathState &s,
             Ray r2 = spawn_ray(s0.p, s0.n, ray.d);
             bool a = true; Hit h; h.prim = 0xffffffffu; h.t = kInf; h.u = h.v = 0.f;
             while (a) {
-                h = trace<false>(sc, r2, stack);
+                h = tr.closest(r2);
                 a = h.prim != 0xffffffffu && sc.shapes[sc.face_shape[h.prim]].emitter >= 0;
                 if (a) { SI s2 = compute_si(sc, r2, h); r2 = spawn_ray(s2.p, s2.n, r2.d); }
             }
@@ -417,7 +454,7 @@ DEV bool path_iteration(const DScene &sc, const DRenderParams &rp, PathState &s,
         if (ds.pdf != 0.f) {                                       // scene.cpp:361-365 test_visibility
             Ray sr = spawn_ray_to(si.p, si.n, ds.p);
             n_shadow++;
-            Hit h = trace<true>(sc, sr, stack);
+            Hit h = tr.any(sr);
             if (h.prim != 0xffffffffu) { em_weight = V3(0.f); ds.pdf = 0.f; }
         }
         active_em = ds.pdf != 0.f;
@@ -465,11 +502,12 @@ k_iterate(DScene sc, DRenderParams rp, DPathStreams qin, DPathStreams qout, DCou
     if (i < n_in) {
         load_state(qin, i, s);
         PCG32 rng; rng.state = s.rng_state; rng.inc = lane_rng_inc(rp.seed_value, s.lane);
-        if (INTEGRATOR == LRT_INTEGRATOR_PATH) alive = path_iteration(sc, rp, s, rng, s_stack + tid, n_shadow);
-        else alive = volpath_iteration(sc, rp, s, rng, s_stack + tid, n_shadow);
+        const GlobalTracer tr{ sc, s_stack + tid };
+        if (INTEGRATOR == LRT_INTEGRATOR_PATH) alive = path_iteration(sc, rp, s, rng, tr, n_shadow);
+        else alive = volpath_iteration(sc, rp, s, rng, tr, n_shadow);
         s.rng_state = rng.state;
-        if (!alive) finish_path(sc, rp, film, sample_out, sample_base, s.lane, s.res, (s.flags & PF_VALID) != 0);
     }
+    finish_paths_wave(sc, rp, film, sample_out, sample_base, i < n_in && !alive, s.lane, s.res, (s.flags & PF_VALID) != 0);
     // ---- compaction: ballot + popcount inside the wave, one queue atomic per workgroup
     const unsigned long long m = __ballot(alive);
     const uint32_t wcount = (uint32_t) __popcll(m);
@@ -491,6 +529,63 @@ k_iterate(DScene sc, DRenderParams rp, DPathStreams qin, DPathStreams qout, DCou
         store_state(qout, slot, s);
     }
     if (tid == 0 && s_shadow) atomicAdd(&cnt->n_shadow, (unsigned long long) s_shadow);
+}
+
+// Persistent variant for scenes whose BVH fits in LDS: one 1024-thread workgroup per CU copies the scene image into
+// LDS once, then pulls 1024-path tiles from a ticket counter until the in-queue is drained.
+template <int INTEGRATOR>
+__global__ void __launch_bounds__(LRT_LDS_BLOCK)
+k_iterate_lds(DScene sc, DRenderParams rp, DLdsInfo li, DPathStreams qin, DPathStreams qout, DCounters *__restrict__ cnt, uint32_t n_in,
+              float *__restrict__ film, float *__restrict__ sample_out, uint64_t sample_base) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ uint32_t s_wave_count[LRT_LDS_BLOCK / 64];
+    __shared__ uint32_t s_base, s_tile;
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane_in_wave = tid & 63u;
+    {
+        const uint4 *src = li.blob; uint4 *dst = reinterpret_cast<uint4 *>(smem);
+        for (uint32_t k = tid; k < li.blob_bytes / 16u; k += LRT_LDS_BLOCK) dst[k] = src[k];
+    }
+    LdsScene L;
+    L.nodes = reinterpret_cast<const float4 *>(smem + li.nodes_off); L.verts = reinterpret_cast<const float4 *>(smem + li.verts_off);
+    L.tris = reinterpret_cast<const uint2 *>(smem + li.tris_off); L.slot_prim = li.slot_prim;
+    L.n_faces = sc.n_faces; L.root_is_leaf = (uint32_t) sc.root_is_leaf; L.root_first = sc.root_leaf_first; L.root_count = sc.root_leaf_count;
+    const LdsTracer tr{ L, reinterpret_cast<uint16_t *>(smem + li.stack_off) + tid };
+    uint32_t n_shadow = 0;
+    __syncthreads();
+    for (;;) {
+        if (tid == 0) s_tile = atomicAdd(&cnt->tile, 1u);
+        __syncthreads();
+        const uint32_t tile = s_tile;
+        if ((uint64_t) tile * LRT_LDS_BLOCK >= n_in) break;
+        const uint32_t i = tile * LRT_LDS_BLOCK + tid;
+        bool alive = false;
+        PathState s;
+        if (i < n_in) {
+            load_state(qin, i, s);
+            PCG32 rng; rng.state = s.rng_state; rng.inc = lane_rng_inc(rp.seed_value, s.lane);
+            if (INTEGRATOR == LRT_INTEGRATOR_PATH) alive = path_iteration(sc, rp, s, rng, tr, n_shadow);
+            else alive = volpath_iteration(sc, rp, s, rng, tr, n_shadow);
+            s.rng_state = rng.state;
+        }
+        finish_paths_wave(sc, rp, film, sample_out, sample_base, i < n_in && !alive, s.lane, s.res, (s.flags & PF_VALID) != 0);
+        const unsigned long long m = __ballot(alive);
+        const uint32_t wprefix = (uint32_t) __popcll(m & ((1ull << lane_in_wave) - 1ull));
+        if (lane_in_wave == 0) s_wave_count[wave] = (uint32_t) __popcll(m);
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t total = 0;
+            for (int w = 0; w < LRT_LDS_BLOCK / 64; ++w) total += s_wave_count[w];
+            s_base = total ? atomicAdd(&cnt->n_out, total) : 0u;
+        }
+        __syncthreads();
+        if (alive) {
+            uint32_t slot = s_base + wprefix;
+            for (uint32_t w = 0; w < wave; ++w) slot += s_wave_count[w];
+            store_state(qout, slot, s);
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) n_shadow += __shfl_down(n_shadow, off);
+    if (lane_in_wave == 0 && n_shadow) atomicAdd(&cnt->n_shadow, (unsigned long long) n_shadow);
 }
 
 // src/films/hdrfilm.cpp:306-410

@@ -23,8 +23,9 @@ DEV float hg_dlog_dg(float g, float c) {
 
 // prbvolpath.py:354-444.  Returns emitter_val * transmittance; seg_sum[c] accumulates -t_seg * scale over the
 // medium segments the reference backpropagates through (segments that end on a surface with tr_c > 0, :425-427).
+template <typename TR>
 DEV V3 prb_sample_emitter(const DScene &sc, PCG32 &rng, V3 ref_p, V3 ref_n, bool ref_is_surface, uint32_t ref_shape, V3 ref_geo_n,
-                          int medium, uint32_t channel, DirSample *ds_out, int *stack, uint32_t &n_shadow, V3 *seg_sum) {
+                          int medium, uint32_t channel, DirSample *ds_out, const TR &tr, uint32_t &n_shadow, V3 *seg_sum) {
     float sx = rng.next(), sy = rng.next();
     DirSample ds; V3 emitter_val = sample_emitter_direction(sc, ref_p, sx, sy, &ds);
     *ds_out = ds;
@@ -41,7 +42,7 @@ DEV V3 prb_sample_emitter(const DScene &sc, PCG32 &rng, V3 ref_p, V3 ref_n, bool
         ray.maxt = remaining_dist;
         active = active && remaining_dist > 0.f;
         needs_intersection = needs_intersection && active;
-        if (needs_intersection) { n_shadow++; Hit h = trace<false>(sc, ray, stack); si = compute_si(sc, ray, h); }
+        if (needs_intersection) { n_shadow++; Hit h = tr.closest(ray); si = compute_si(sc, ray, h); }
         needs_intersection = false;
         bool active_medium = active && medium >= 0, active_surface = active && !active_medium;
         V3 tr_multiplier(1.f);
@@ -76,8 +77,8 @@ DEV V3 prb_sample_emitter(const DScene &sc, PCG32 &rng, V3 ref_p, V3 ref_n, bool
 
 // One trip of prbvolpath's loop (prbvolpath.py:139-349).  s.res holds L: accumulated radiance (primal) or the
 // radiance still to be collected (adjoint).  Returns true when the path survives.
-template <bool ADJOINT>
-DEV bool prb_iteration(const DScene &sc, const DRenderParams &rp, PathState &s, PCG32 &rng, int *stack, uint32_t &n_shadow,
+template <bool ADJOINT, typename TR>
+DEV bool prb_iteration(const DScene &sc, const DRenderParams &rp, PathState &s, PCG32 &rng, const TR &tr, uint32_t &n_shadow,
                        V3 delta_L, PrbGrads &G) {
     uint32_t depth = s.flags & PF_DEPTH_MASK;
     int medium = (int) ((s.flags & PF_MEDIUM_MASK) >> PF_MEDIUM_SHIFT) - 1;
@@ -107,7 +108,7 @@ DEV bool prb_iteration(const DScene &sc, const DRenderParams &rp, PathState &s, 
         const DMedium M = sc.media[medium];
         mei = medium_sample_interaction(M, ray, rng.next(), channel);
         if (mei.valid()) ray.maxt = mei.t;
-        { Hit h = trace<false>(sc, ray, stack); si = compute_si(sc, ray, h); }
+        { Hit h = tr.closest(ray); si = compute_si(sc, ray, h); }
         if (si.t < mei.t) mei.t = kInf;
         seg_t = fmin_(mei.t, si.t) - mei.mint;
         V3 tr(m_exp(-seg_t * mei.combined.x), m_exp(-seg_t * mei.combined.y), m_exp(-seg_t * mei.combined.z));
@@ -139,12 +140,12 @@ DEV bool prb_iteration(const DScene &sc, const DRenderParams &rp, PathState &s, 
     // ---- surface interactions
     active_surface = active_surface || escaped_medium;
     bool intersect = active_surface && !escaped_medium;
-    if (intersect) { Hit h = trace<false>(sc, ray, stack); si = compute_si(sc, ray, h); }
+    if (intersect) { Hit h = tr.closest(ray); si = compute_si(sc, ray, h); }
     if (rp.hide_emitters && intersect && depth == 0 && si.valid && sc.shapes[si.shape].emitter >= 0) {
         Ray r2 = spawn_ray(si.p, si.n, ray.d);
         bool a = true; Hit h; h.prim = 0xffffffffu; h.t = kInf; h.u = h.v = 0.f;
         while (a) {
-            h = trace<false>(sc, r2, stack);
+            h = tr.closest(r2);
             a = h.prim != 0xffffffffu && sc.shapes[sc.face_shape[h.prim]].emitter >= 0;
             if (a) { SI s2 = compute_si(sc, r2, h); r2 = spawn_ray(s2.p, s2.n, r2.d); }
         }
@@ -171,7 +172,7 @@ DEV bool prb_iteration(const DScene &sc, const DRenderParams &rp, PathState &s, 
     if (active_e_surface || active_e_medium) {
         DirSample ds; V3 seg_sum;
         V3 rp_ = active_e_medium ? mei.p : si.p, rn = active_e_medium ? V3(0.f) : si.n;
-        V3 emitted = prb_sample_emitter(sc, rng, rp_, rn, active_e_surface, active_e_surface ? si.shape : 0u, si.n, medium, channel, &ds, stack, n_shadow, &seg_sum);
+        V3 emitted = prb_sample_emitter(sc, rng, rp_, rn, active_e_surface, active_e_surface ? si.shape : 0u, si.n, medium, channel, &ds, tr, n_shadow, &seg_sum);
         V3 nee_weight; float nee_pdf;
         if (active_e_surface) { V3 wo = si.sh.to_local(ds.d); nee_weight = bsdf_eval(sc, b, si, wo); nee_pdf = bsdf_pdf(sc, b, si, wo); }
         else { float pv = phase_eval(sc.media[medium], mei.wi, ds.d); nee_weight = V3(pv); nee_pdf = pv; }
@@ -310,7 +311,8 @@ k_iterate_prb(DScene sc, DRenderParams rp, DPathStreams qin, DPathStreams qout, 
     if (i < n_in) {
         load_state(qin, i, s); dl = dl_in[i];
         PCG32 rng; rng.state = s.rng_state; rng.inc = lane_rng_inc(rp.seed_value, s.lane);
-        alive = prb_iteration<ADJOINT>(sc, rp, s, rng, s_stack + tid, n_shadow, V3(dl.x, dl.y, dl.z), G);
+        const GlobalTracer tr{ sc, s_stack + tid };
+        alive = prb_iteration<ADJOINT>(sc, rp, s, rng, tr, n_shadow, V3(dl.x, dl.y, dl.z), G);
         s.rng_state = rng.state;
         if (!alive && !ADJOINT) {
             if (L_buf) L_buf[f2u(dl.w)] = make_float4(s.res.x, s.res.y, s.res.z, (s.flags & PF_VALID) ? 1.f : 0.f);
