@@ -41,7 +41,7 @@ struct DeviceScene {
     uint32_t *pixel_list = nullptr; uint32_t pixel_list_rank = 0xffffffffu, pixel_list_count = 0, n_owned_pixels = 0;
     std::vector<hipEvent_t> ev_pool;
     std::vector<DMedium> h_media; DMedium *d_media = nullptr;
-    DLdsInfo lds{}; bool use_lds = false; int n_cus = 256;
+    DLdsInfo lds{}; bool use_lds = false; int n_cus = 256; int lds_block = 1024;
 
     template <typename T> T *track(T *p) { allocs.push_back((void *) p); return p; }
     ~DeviceScene() {
@@ -178,7 +178,8 @@ DeviceScene *device_scene_create(const lrt_scene_desc &d, int device) {
         hipDeviceProp_t prop; HIP_CHECK(hipGetDeviceProperties(&prop, device)); D->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         const size_t n_nodes = bvh.nodes.size() / 16, n_slots = bvh.tris.size() / 12, n_verts = d.n_vertices;
         const size_t nodes_b = n_nodes * 64, verts_b = (n_verts * 16 + 15) & ~size_t(15), tris_b = (n_slots * 8 + 15) & ~size_t(15);
-        const size_t stack_b = (size_t) 2 * LRT_LDS_STACK * LRT_LDS_BLOCK, total = nodes_b + verts_b + tris_b + stack_b;
+        D->lds_block = getenv("LRT_LDS_BLOCK") ? atoi(getenv("LRT_LDS_BLOCK")) : 1024; if (D->lds_block != 512) D->lds_block = 1024;
+        const size_t stack_b = (size_t) 2 * LRT_LDS_STACK * D->lds_block, total = nodes_b + verts_b + tris_b + stack_b;
         const size_t lds_limit = std::min<size_t>((size_t) prop.sharedMemPerBlock ? 160 * 1024 : 64 * 1024, 160 * 1024) - 512;
         if (d.n_faces > 0 && n_verts <= 65535 && n_nodes <= 32767 && bvh.max_depth < LRT_LDS_STACK && total <= lds_limit && !getenv("LRT_NO_LDS_BVH")) {
             std::vector<unsigned char> blob(nodes_b + verts_b + tris_b, 0);
@@ -195,8 +196,10 @@ DeviceScene *device_scene_create(const lrt_scene_desc &d, int device) {
             D->lds.slot_prim = D->track(dev_upload(slot_prim.data(), slot_prim.size(), st));
             D->lds.blob_bytes = (uint32_t) blob.size(); D->lds.nodes_off = 0; D->lds.verts_off = (uint32_t) nodes_b; D->lds.tris_off = (uint32_t) (nodes_b + verts_b);
             D->lds.stack_off = (uint32_t) blob.size(); D->lds.total_bytes = (uint32_t) total;
-            HIP_CHECK(hipFuncSetAttribute((const void *) k_iterate_lds<LRT_INTEGRATOR_PATH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) total));
-            HIP_CHECK(hipFuncSetAttribute((const void *) k_iterate_lds<LRT_INTEGRATOR_VOLPATH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) total));
+            HIP_CHECK(hipFuncSetAttribute((const void *) k_iterate_lds<LRT_INTEGRATOR_PATH, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) total));
+            HIP_CHECK(hipFuncSetAttribute((const void *) k_iterate_lds<LRT_INTEGRATOR_VOLPATH, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) total));
+            HIP_CHECK(hipFuncSetAttribute((const void *) k_iterate_lds<LRT_INTEGRATOR_PATH, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) total));
+            HIP_CHECK(hipFuncSetAttribute((const void *) k_iterate_lds<LRT_INTEGRATOR_VOLPATH, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) total));
             D->use_lds = true;
         }
     }
@@ -256,7 +259,7 @@ DeviceScene *device_scene_create(const lrt_scene_desc &d, int device) {
         } else { E.bsphere_c[0] = E.bsphere_c[1] = E.bsphere_c[2] = 0.f; E.bsphere_r = ray_eps; }
     }
     // ---- emitters
-    std::vector<DEmitter> em(d.n_emitters); std::vector<float> env_rgbx, hier;
+    std::vector<DEmitter> em(d.n_emitters); std::vector<float> env_rgbx, hier; bool env_interior_positive = false;
     for (uint32_t i = 0; i < d.n_emitters; ++i) {
         const lrt_emitter_desc &S = d.emitters[i]; DEmitter &o = em[i]; memset(&o, 0, sizeof(o));
         o.type = S.type; o.shape = S.shape; o.scale = S.scale; for (int k = 0; k < 3; ++k) o.radiance[k] = S.radiance[k];
@@ -289,11 +292,16 @@ DeviceScene *device_scene_create(const lrt_scene_desc &d, int device) {
                     for (int k = 0; k < 3; ++k) env_rgbx[((size_t) y * E.w + w) * 4 + k] = env_rgbx[((size_t) y * E.w) * 4 + k];
                 }
                 build_hierarchy(lum, E.w, h, E, hier);
+                env_interior_positive = true;          // rows 1..h-2 of the sampling density strictly positive?
+                for (uint32_t y = 1; y + 1 < h && env_interior_positive; ++y)
+                    for (uint32_t x = 0; x < E.w; ++x) if (!(lum[(size_t) y * E.w + x] > 0.f)) { env_interior_positive = false; break; }
                 for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) E.to_world[3 * a + b] = S.to_world[4 * a + b];
                 inverse3(S.to_world, E.to_local);
             }
         }
     }
+    sc.nee_fast_reject = (d.n_emitters == 1 && !sc.has_null_bsdf && !getenv("LRT_NO_NEE_REJECT") &&
+                          (E.type == LRT_EMITTER_CONSTANT || (E.type == LRT_EMITTER_ENVMAP && env_interior_positive))) ? 1 : 0;
     sc.emitters = D->track(dev_upload(em.data(), em.size(), st));
     sc.env_data = (const float4 *) D->track(dev_upload(env_rgbx.data(), env_rgbx.size(), st));
     sc.env_hier = D->track(dev_upload(hier.data(), hier.size(), st));
@@ -376,7 +384,7 @@ static DRenderParams make_params(const lrt_scene_desc &d, const ResolvedOpts &O,
     return rp;
 }
 
-struct LaunchLog { std::vector<std::pair<hipEvent_t, hipEvent_t>> launches; size_t ev = 0; uint64_t n_iter = 0; };
+struct LaunchLog { std::vector<std::pair<hipEvent_t, hipEvent_t>> launches; std::vector<uint32_t> sizes; size_t ev = 0; uint64_t n_iter = 0; };
 
 // Drains one chunk of `n` freshly generated paths sitting in q[0]: launches `iterate(cur, n)` until the queue is empty.
 template <typename Iterate>
@@ -389,7 +397,7 @@ static void drain_chunk(DeviceScene *D, uint32_t n, LaunchLog &log, bool count_i
         HIP_CHECK(hipEventRecord(a, st));
         iterate(cur, n);
         HIP_CHECK(hipEventRecord(b, st));
-        log.launches.emplace_back(a, b);
+        log.launches.emplace_back(a, b); log.sizes.push_back(n);
         HIP_CHECK(hipMemcpyAsync(D->h_counters, D->counters, sizeof(DCounters), hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));
         if (count_iter) log.n_iter += n;
@@ -415,7 +423,10 @@ static void finish_stats(DeviceScene *D, LaunchLog &log, hipEvent_t e_begin, hip
     HIP_CHECK(hipGetLastError());
     stats.n_samples = n_lanes; stats.n_iter = log.n_iter; stats.n_shadow = D->h_counters->n_shadow; stats.n_launches = log.launches.size();
     float ms = 0.f; double ksum = 0.0;
-    for (auto &l : log.launches) { HIP_CHECK(hipEventElapsedTime(&ms, l.first, l.second)); ksum += ms; }
+    for (size_t i = 0; i < log.launches.size(); ++i) {
+        HIP_CHECK(hipEventElapsedTime(&ms, log.launches[i].first, log.launches[i].second)); ksum += ms;
+        if (getenv("LRT_DEBUG_LAUNCH") && i < 40) fprintf(stderr, "[lrt] launch %zu: n=%u %.3f ms (%.2f Gpath-iter/s)\n", i, log.sizes[i], ms, log.sizes[i] / ms * 1e-6);
+    }
     stats.kernel_ms = ksum;
     HIP_CHECK(hipEventElapsedTime(&ms, e_begin, e_end)); stats.total_ms = ms;
 }
@@ -435,26 +446,52 @@ static void run_wavefront(DeviceScene *D, const lrt_scene_desc &d, const Resolve
     HIP_CHECK(hipEventRecord(e_begin, st));
     // path.cpp:103-104 returns before the loop when max_depth == 0: that launch only retires the lanes
     const bool count_iter = !(O.integrator == LRT_INTEGRATOR_PATH && O.max_depth == 0);
-    for (uint64_t base = 0; base < n_lanes; base += chunk) {
-        uint32_t n = (uint32_t) std::min<uint64_t>(chunk, n_lanes - base);
-        uint32_t grid0 = (n + LRT_BLOCK - 1) / LRT_BLOCK;
-        if (prb) k_raygen_prb<false><<<grid0, LRT_BLOCK, 0, st>>>(D->sc, rp, D->q[0], D->dl[0], pixel_list, lane_begin + base, n, nullptr, nullptr, nullptr);
-        else k_raygen<<<grid0, LRT_BLOCK, 0, st>>>(D->sc, rp, D->q[0], pixel_list, lane_begin + base, n, 0);
-        drain_chunk(D, n, log, count_iter, [&](int cur, uint32_t m) {
-            uint32_t grid = (m + LRT_BLOCK - 1) / LRT_BLOCK;
-            if (prb)
+    if (prb) {
+        for (uint64_t base = 0; base < n_lanes; base += chunk) {
+            uint32_t n = (uint32_t) std::min<uint64_t>(chunk, n_lanes - base);
+            uint32_t grid0 = (n + LRT_BLOCK - 1) / LRT_BLOCK;
+            k_raygen_prb<false><<<grid0, LRT_BLOCK, 0, st>>>(D->sc, rp, D->q[0], D->dl[0], pixel_list, lane_begin + base, n, nullptr, nullptr, nullptr);
+            drain_chunk(D, n, log, count_iter, [&](int cur, uint32_t m) {
+                uint32_t grid = (m + LRT_BLOCK - 1) / LRT_BLOCK;
                 k_iterate_prb<false><<<grid, LRT_BLOCK, 0, st>>>(D->sc, rp, D->q[cur], D->q[cur ^ 1], D->dl[cur], D->dl[cur ^ 1], D->counters, m, nullptr, nullptr, film, sample_out, lane_begin);
-            else if (D->use_lds) {
-                uint32_t g = std::min<uint32_t>((uint32_t) D->n_cus, (m + LRT_LDS_BLOCK - 1) / LRT_LDS_BLOCK);
-                if (O.integrator == LRT_INTEGRATOR_PATH)
-                    k_iterate_lds<LRT_INTEGRATOR_PATH><<<g, LRT_LDS_BLOCK, D->lds.total_bytes, st>>>(D->sc, rp, D->lds, D->q[cur], D->q[cur ^ 1], D->counters, m, film, sample_out, lane_begin);
-                else
-                    k_iterate_lds<LRT_INTEGRATOR_VOLPATH><<<g, LRT_LDS_BLOCK, D->lds.total_bytes, st>>>(D->sc, rp, D->lds, D->q[cur], D->q[cur ^ 1], D->counters, m, film, sample_out, lane_begin);
-            } else if (O.integrator == LRT_INTEGRATOR_PATH)
-                k_iterate<LRT_INTEGRATOR_PATH><<<grid, LRT_BLOCK, 0, st>>>(D->sc, rp, D->q[cur], D->q[cur ^ 1], D->counters, m, film, sample_out, lane_begin);
-            else
-                k_iterate<LRT_INTEGRATOR_VOLPATH><<<grid, LRT_BLOCK, 0, st>>>(D->sc, rp, D->q[cur], D->q[cur ^ 1], D->counters, m, film, sample_out, lane_begin);
-        });
+            });
+        }
+        finish_stats(D, log, e_begin, e_end, n_lanes, stats);
+        return;
+    }
+    // Streaming regeneration: every launch first tops the in-queue up with fresh camera rays (back region), so launches stay
+    // full until the lanes run out; the two-region queue keeps in-medium and surface paths in separate tiles.
+    const uint32_t cap = D->capacity;
+    uint64_t next = 0; uint32_t n_m = 0, n_s = 0; int cur = 0;
+    while (next < n_lanes || n_m + n_s > 0) {
+        const uint32_t fresh = (uint32_t) std::min<uint64_t>(n_lanes - next, chunk - (n_m + n_s));
+        if (fresh) {
+            k_raygen<<<(fresh + LRT_BLOCK - 1) / LRT_BLOCK, LRT_BLOCK, 0, st>>>(D->sc, rp, D->q[cur], pixel_list, lane_begin + next, fresh, n_s, cap);
+            next += fresh; n_s += fresh;
+        }
+        HIP_CHECK(hipMemsetAsync(&D->counters->n_out, 0, 3 * sizeof(uint32_t), st));      // n_out, tile ticket, n_out_s
+        hipEvent_t a = get_event(D, log.ev++), b = get_event(D, log.ev++);
+        HIP_CHECK(hipEventRecord(a, st));
+        const bool isp = O.integrator == LRT_INTEGRATOR_PATH;
+        if (D->use_lds) {
+            const uint32_t B = (uint32_t) D->lds_block;
+            const uint32_t g = std::min<uint32_t>((uint32_t) D->n_cus, (n_m + B - 1) / B + (n_s + B - 1) / B);
+            #define LRT_LAUNCH_LDS(I, BS) k_iterate_lds<I, BS><<<g, BS, D->lds.total_bytes, st>>>(D->sc, rp, D->lds, D->q[cur], D->q[cur ^ 1], D->counters, n_m, n_s, cap, film, sample_out, lane_begin)
+            if (B == 512) { if (isp) LRT_LAUNCH_LDS(LRT_INTEGRATOR_PATH, 512); else LRT_LAUNCH_LDS(LRT_INTEGRATOR_VOLPATH, 512); }
+            else { if (isp) LRT_LAUNCH_LDS(LRT_INTEGRATOR_PATH, 1024); else LRT_LAUNCH_LDS(LRT_INTEGRATOR_VOLPATH, 1024); }
+            #undef LRT_LAUNCH_LDS
+        } else {
+            const uint32_t grid = (n_m + LRT_BLOCK - 1) / LRT_BLOCK + (n_s + LRT_BLOCK - 1) / LRT_BLOCK;
+            if (isp) k_iterate<LRT_INTEGRATOR_PATH><<<grid, LRT_BLOCK, 0, st>>>(D->sc, rp, D->q[cur], D->q[cur ^ 1], D->counters, n_m, n_s, cap, film, sample_out, lane_begin);
+            else k_iterate<LRT_INTEGRATOR_VOLPATH><<<grid, LRT_BLOCK, 0, st>>>(D->sc, rp, D->q[cur], D->q[cur ^ 1], D->counters, n_m, n_s, cap, film, sample_out, lane_begin);
+        }
+        HIP_CHECK(hipEventRecord(b, st));
+        log.launches.emplace_back(a, b); log.sizes.push_back(n_m + n_s);
+        HIP_CHECK(hipMemcpyAsync(D->h_counters, D->counters, sizeof(DCounters), hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        if (count_iter) log.n_iter += n_m + n_s;
+        n_m = D->h_counters->n_out; n_s = D->h_counters->n_out_s;
+        cur ^= 1;
     }
     finish_stats(D, log, e_begin, e_end, n_lanes, stats);
 }

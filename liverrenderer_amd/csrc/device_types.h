@@ -85,6 +85,7 @@ struct DScene {
     const float *env_hier;
     uint32_t n_faces, n_emitters;
     int32_t root_is_leaf, has_null_bsdf;
+    int32_t nee_fast_reject, pad0;   // see volpath_iteration(): in-medium NEE can be rejected before sampling the emitter
     uint32_t root_leaf_first, root_leaf_count;
     DCamera cam; DFilm film; DEnv env;
 };
@@ -118,8 +119,8 @@ struct DPathStreams {
 #define PF_VALID        (1u << 27)
 
 struct DCounters {             // device-resident queue / statistics words
-    uint32_t n_in, n_out;
-    uint32_t tile, pad;        // tile: work-distribution ticket of the persistent kernel
+    uint32_t n_in, n_out;      // n_out: survivors that continue inside a medium (front region of the out queue)
+    uint32_t tile, n_out_s;    // tile: work ticket of the persistent kernel; n_out_s: survivors outside media (back region)
     unsigned long long n_shadow;
     unsigned long long n_iter;
 };

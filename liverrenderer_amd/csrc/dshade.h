@@ -104,7 +104,7 @@ struct LdsScene {
     uint32_t n_faces, root_is_leaf, root_first, root_count;
 };
 #define LRT_LDS_STACK 24
-#define LRT_LDS_BLOCK 1024
+#define LRT_LDS_BLOCK_MAX 1024
 
 DEV void test_tri_lds(const LdsScene &L, uint32_t slot, V3 o, V3 d, float maxt, Hit &best) {
     uint2 ix = L.tris[slot];
@@ -125,7 +125,7 @@ DEV void test_tri_lds(const LdsScene &L, uint32_t slot, V3 o, V3 d, float maxt, 
     if (t < best.t || f < best.prim) { best.t = t; best.u = u; best.v = v; best.prim = f; }
 }
 
-template <bool ANY_HIT>
+template <bool ANY_HIT, int STRIDE>
 DEV Hit trace_lds(const LdsScene &L, const Ray &r, uint16_t *__restrict__ stack /* &lds_stack[threadIdx.x] */) {
     Hit best; best.t = kInf; best.u = best.v = 0.f; best.prim = 0xffffffffu;
     if (L.n_faces == 0) return best;
@@ -134,20 +134,22 @@ DEV Hit trace_lds(const LdsScene &L, const Ray &r, uint16_t *__restrict__ stack 
         for (uint32_t i = 0; i < L.root_count; ++i) test_tri_lds(L, L.root_first + i, o, d, r.maxt, best);
         return best;
     }
-    const float ix = 1.f / d.x, iy = 1.f / d.y, iz = 1.f / d.z;
+    // The slab arithmetic only culls (hits are decided by the Moeller-Trumbore tests and the tie rule), so it may differ
+    // from the oracle's: approximate reciprocal, one fma per plane, 3-input min/max.  The padded boxes absorb the error.
+    const float ix = __builtin_amdgcn_rcpf(d.x), iy = __builtin_amdgcn_rcpf(d.y), iz = __builtin_amdgcn_rcpf(d.z);
+    const float ox = -o.x * ix, oy = -o.y * iy, oz = -o.z * iz;
     int sp = 0, node = 0;
     for (;;) {
         const float4 *nd = L.nodes + 4 * node;
         float4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3];
         float limit = fmin_(best.t, r.maxt);
-        float t0, t1, tmin0, tmax0, tmin1, tmax1;
-        t0 = (n0.x - o.x) * ix; t1 = (n0.y - o.x) * ix; tmin0 = fmax_(0.f, fmin_(t0, t1)); tmax0 = fmin_(limit, fmax_(t0, t1));
-        t0 = (n0.z - o.y) * iy; t1 = (n0.w - o.y) * iy; tmin0 = fmax_(tmin0, fmin_(t0, t1)); tmax0 = fmin_(tmax0, fmax_(t0, t1));
-        t0 = (n2.x - o.z) * iz; t1 = (n2.y - o.z) * iz; tmin0 = fmax_(tmin0, fmin_(t0, t1)); tmax0 = fmin_(tmax0, fmax_(t0, t1));
-        t0 = (n1.x - o.x) * ix; t1 = (n1.y - o.x) * ix; tmin1 = fmax_(0.f, fmin_(t0, t1)); tmax1 = fmin_(limit, fmax_(t0, t1));
-        t0 = (n1.z - o.y) * iy; t1 = (n1.w - o.y) * iy; tmin1 = fmax_(tmin1, fmin_(t0, t1)); tmax1 = fmin_(tmax1, fmax_(t0, t1));
-        t0 = (n2.z - o.z) * iz; t1 = (n2.w - o.z) * iz; tmin1 = fmax_(tmin1, fmin_(t0, t1)); tmax1 = fmin_(tmax1, fmax_(t0, t1));
-        bool h0 = tmin0 <= tmax0 * 1.0000005f + 1e-30f, h1 = tmin1 <= tmax1 * 1.0000005f + 1e-30f;
+        float ax0 = fma_(n0.x, ix, ox), ax1 = fma_(n0.y, ix, ox), ay0 = fma_(n0.z, iy, oy), ay1 = fma_(n0.w, iy, oy), az0 = fma_(n2.x, iz, oz), az1 = fma_(n2.y, iz, oz);
+        float bx0 = fma_(n1.x, ix, ox), bx1 = fma_(n1.y, ix, ox), by0 = fma_(n1.z, iy, oy), by1 = fma_(n1.w, iy, oy), bz0 = fma_(n2.z, iz, oz), bz1 = fma_(n2.w, iz, oz);
+        float tmin0 = fmax_(fmax_(fmin_(ax0, ax1), fmin_(ay0, ay1)), fmax_(fmin_(az0, az1), 0.f));
+        float tmax0 = fmin_(fmin_(fmax_(ax0, ax1), fmax_(ay0, ay1)), fmin_(fmax_(az0, az1), limit));
+        float tmin1 = fmax_(fmax_(fmin_(bx0, bx1), fmin_(by0, by1)), fmax_(fmin_(bz0, bz1), 0.f));
+        float tmax1 = fmin_(fmin_(fmax_(bx0, bx1), fmax_(by0, by1)), fmin_(fmax_(bz0, bz1), limit));
+        bool h0 = tmin0 <= tmax0 * 1.000002f + 1e-30f, h1 = tmin1 <= tmax1 * 1.000002f + 1e-30f;
         int r0 = (int) f2u(n3.x), r1 = (int) f2u(n3.y);
         int next = 0x7fffffff;
         if (h0 && h1) {
@@ -156,7 +158,7 @@ DEV Hit trace_lds(const LdsScene &L, const Ray &r, uint16_t *__restrict__ stack 
             int nearc = swap ? (int) f2u(n3.w) : (int) f2u(n3.z), farc = swap ? (int) f2u(n3.z) : (int) f2u(n3.w);
             if (nearr < 0) { uint32_t first = (uint32_t) ~nearr; for (int i = 0; i < nearc; ++i) test_tri_lds(L, first + i, o, d, r.maxt, best); }
             if (farr < 0) { uint32_t first = (uint32_t) ~farr; for (int i = 0; i < farc; ++i) test_tri_lds(L, first + i, o, d, r.maxt, best); }
-            if (nearr >= 0) { next = nearr; if (farr >= 0) { stack[sp * LRT_LDS_BLOCK] = (uint16_t) farr; ++sp; } }
+            if (nearr >= 0) { next = nearr; if (farr >= 0) { stack[sp * STRIDE] = (uint16_t) farr; ++sp; } }
             else if (farr >= 0) next = farr;
         } else if (h0 || h1) {
             int rr = h0 ? r0 : r1, cc = h0 ? (int) f2u(n3.z) : (int) f2u(n3.w);
@@ -166,17 +168,18 @@ DEV Hit trace_lds(const LdsScene &L, const Ray &r, uint16_t *__restrict__ stack 
         if (ANY_HIT && best.prim != 0xffffffffu) return best;
         if (next == 0x7fffffff) {
             if (sp == 0) break;
-            --sp; next = stack[sp * LRT_LDS_BLOCK];
+            --sp; next = stack[sp * STRIDE];
         }
         node = next;
     }
     return best;
 }
 
+template <int STRIDE>
 struct LdsTracer {
     const LdsScene &L; uint16_t *stack;
-    DEV Hit closest(const Ray &r) const { return trace_lds<false>(L, r, stack); }
-    DEV Hit any(const Ray &r) const { return trace_lds<true>(L, r, stack); }
+    DEV Hit closest(const Ray &r) const { return trace_lds<false, STRIDE>(L, r, stack); }
+    DEV Hit any(const Ray &r) const { return trace_lds<true, STRIDE>(L, r, stack); }
 };
 
 // --------------------------------------------------- surface interaction

@@ -73,7 +73,7 @@ DEV Ray camera_ray(const DScene &sc, float ax, float ay) {
 
 __global__ void __launch_bounds__(LRT_BLOCK)
 k_raygen(DScene sc, DRenderParams rp, DPathStreams q, const uint32_t *__restrict__ pixel_list,
-         uint64_t lane_base, uint32_t n, uint32_t slot_base) {
+         uint64_t lane_base, uint32_t n, uint32_t back_base, uint32_t cap) {
     uint32_t i = blockIdx.x * LRT_BLOCK + threadIdx.x;
     if (i >= n) return;
     uint64_t j = lane_base + i;                       // rank-local lane
@@ -97,7 +97,7 @@ k_raygen(DScene sc, DRenderParams rp, DPathStreams q, const uint32_t *__restrict
         flags |= (uint32_t) (sc.cam.medium + 1) << PF_MEDIUM_SHIFT;
     }
     s.flags = flags; s.rng_state = rng.state;
-    store_state(q, slot_base + i, s);
+    store_state(q, cap - 1u - (back_base + i), s);          // camera rays start outside media: back region of the queue
 }
 
 // ------------------------------------------------------------------ film
@@ -326,11 +326,32 @@ DEV bool volpath_iteration(const DScene &sc, const DRenderParams &rp, PathState 
         valid_ray = true;
         specular_chain = !sample_emitters;
         if (sample_emitters) {
-            DirSample ds;
-            V3 emitted = volpath_sample_emitter(sc, rng, mei.p, V3(0.f), false, 0, V3(0.f), medium, channel, &ds, tr, n_shadow);
-            float phase_val = phase_eval(M, mei.wi, ds.d);
-            V3 c = throughput * phase_val * emitted * mis_weight(ds.pdf, ds.delta ? 0.f : phase_val);
-            result = result + c;
+            // Exact early rejection (sc.nee_fast_reject: one infinite emitter, no null BSDF in the scene).  The emitter
+            // sample lies at distance 2*max(r_bsphere, |p - c|) whatever its direction (envmap.cpp:431-433,
+            // constant.cpp sample_direction), the march draws ONE free-flight distance, and a collision inside the
+            // segment zeroes the sample (sigma_n = 0; every surface blocks).  So when the free-flight distance is
+            // safely below that bound the contribution is exactly 0 and only the three random numbers are consumed.
+            // The guards keep (sx, sy) away from the map's border rows/columns, the only place where the sampled
+            // density can be 0 (which would skip the third draw); everything else takes the full routine.
+            bool rejected = false;
+            if (sc.nee_fast_reject) {
+                PCG32 saved = rng;
+                float sx = rng.next(), sy = rng.next(), u3 = rng.next();
+                const float lo = 9.5367431640625e-7f, hi = 1.f - 9.5367431640625e-7f;
+                bool interior = sc.env.type == LRT_EMITTER_CONSTANT || (sx > lo && sx < hi && sy > lo && sy < hi);
+                float sampled_t = 0.f + (-m_log(1.f - u3) / idx3(V3(M.sigma_t[0], M.sigma_t[1], M.sigma_t[2]), channel));
+                V3 cc(sc.env.bsphere_c[0], sc.env.bsphere_c[1], sc.env.bsphere_c[2]);
+                float dist = 2.f * fmax_(sc.env.bsphere_r, norm(mei.p - cc));
+                rejected = interior && sampled_t <= dist * 0.998f - 1e-3f;
+                if (!rejected) rng = saved;
+            }
+            if (!rejected) {
+                DirSample ds;
+                V3 emitted = volpath_sample_emitter(sc, rng, mei.p, V3(0.f), false, 0, V3(0.f), medium, channel, &ds, tr, n_shadow);
+                float phase_val = phase_eval(M, mei.wi, ds.d);
+                V3 c = throughput * phase_val * emitted * mis_weight(ds.pdf, ds.delta ? 0.f : phase_val);
+                result = result + c;
+            }
         }
         (void) rng.next();
         float s2x = rng.next(), s2y = rng.next();
@@ -485,21 +506,56 @@ DEV bool path_iteration(const DScene &sc, const DRenderParams &rp, PathState &s,
     return active;
 }
 
+// ---- queues.  A queue (one set of path streams of `cap` records) holds two regions: paths that are inside a medium grow
+// from the front ([0, n_m)), all other paths (camera rays, paths outside media) from the back (record cap-1-j, j in [0, n_s)).
+// Tiles never mix the two populations, which keeps a wave's lanes on the same branch of the loop body.
+DEV uint32_t queue_index(uint32_t tile, uint32_t tid, uint32_t B, uint32_t n_m, uint32_t n_s, uint32_t cap, bool *valid) {
+    const uint32_t tiles_m = (n_m + B - 1) / B;
+    if (tile < tiles_m) { uint32_t i = tile * B + tid; *valid = i < n_m; return i; }
+    uint32_t j = (tile - tiles_m) * B + tid; *valid = j < n_s; return cap - 1u - j;
+}
+
+// Retires finished paths into the film and appends survivors to the out queue: __ballot + popcount prefix inside the
+// wave, one atomic per region and workgroup.  Called by every thread of the workgroup (two barriers inside).
+template <int B>
+DEV void retire_and_compact(const DScene &sc, const DRenderParams &rp, bool had_path, bool alive, const PathState &s,
+                            float *__restrict__ film, float *__restrict__ sample_out, uint64_t sample_base,
+                            const DPathStreams &qout, uint32_t cap, DCounters *__restrict__ cnt,
+                            uint32_t *s_wc_m, uint32_t *s_wc_s, uint32_t *s_base /* [2] */) {
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane_in_wave = tid & 63u;
+    finish_paths_wave(sc, rp, film, sample_out, sample_base, had_path && !alive, s.lane, s.res, (s.flags & PF_VALID) != 0);
+    const bool in_medium = (s.flags & PF_MEDIUM_MASK) != 0;
+    const unsigned long long mm = __ballot(alive && in_medium), ms = __ballot(alive && !in_medium);
+    const unsigned long long below = (1ull << lane_in_wave) - 1ull;
+    if (lane_in_wave == 0) { s_wc_m[wave] = (uint32_t) __popcll(mm); s_wc_s[wave] = (uint32_t) __popcll(ms); }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t tm = 0, ts = 0;
+        for (int w = 0; w < B / 64; ++w) { tm += s_wc_m[w]; ts += s_wc_s[w]; }
+        s_base[0] = tm ? atomicAdd(&cnt->n_out, tm) : 0u;
+        s_base[1] = ts ? atomicAdd(&cnt->n_out_s, ts) : 0u;
+    }
+    __syncthreads();
+    if (alive) {
+        uint32_t slot = in_medium ? s_base[0] + (uint32_t) __popcll(mm & below) : s_base[1] + (uint32_t) __popcll(ms & below);
+        for (uint32_t w = 0; w < wave; ++w) slot += in_medium ? s_wc_m[w] : s_wc_s[w];
+        store_state(qout, in_medium ? slot : cap - 1u - slot, s);
+    }
+}
+
+// Grid-launched variant: BVH in global memory (any scene size), one 256-path tile per workgroup.
 template <int INTEGRATOR>
 __global__ void __launch_bounds__(LRT_BLOCK)
-k_iterate(DScene sc, DRenderParams rp, DPathStreams qin, DPathStreams qout, DCounters *__restrict__ cnt, uint32_t n_in,
+k_iterate(DScene sc, DRenderParams rp, DPathStreams qin, DPathStreams qout, DCounters *__restrict__ cnt, uint32_t n_m, uint32_t n_s, uint32_t cap,
           float *__restrict__ film, float *__restrict__ sample_out, uint64_t sample_base) {
     __shared__ int s_stack[LRT_STACK * LRT_BLOCK];
-    __shared__ uint32_t s_wave_count[LRT_BLOCK / 64];
-    __shared__ uint32_t s_base;
-    __shared__ uint32_t s_shadow;
-    const uint32_t tid = threadIdx.x, i = blockIdx.x * LRT_BLOCK + tid;
-    const uint32_t wave = tid >> 6, lane_in_wave = tid & 63u;
-    if (tid == 0) s_shadow = 0;
+    __shared__ uint32_t s_wc_m[LRT_BLOCK / 64], s_wc_s[LRT_BLOCK / 64], s_base[2];
+    const uint32_t tid = threadIdx.x;
+    bool had_path; const uint32_t i = queue_index(blockIdx.x, tid, LRT_BLOCK, n_m, n_s, cap, &had_path);
     bool alive = false;
-    PathState s;
+    PathState s; s.flags = 0; s.lane = 0; s.res = V3(0.f);
     uint32_t n_shadow = 0;
-    if (i < n_in) {
+    if (had_path) {
         load_state(qin, i, s);
         PCG32 rng; rng.state = s.rng_state; rng.inc = lane_rng_inc(rp.seed_value, s.lane);
         const GlobalTracer tr{ sc, s_stack + tid };
@@ -507,40 +563,21 @@ k_iterate(DScene sc, DRenderParams rp, DPathStreams qin, DPathStreams qout, DCou
         else alive = volpath_iteration(sc, rp, s, rng, tr, n_shadow);
         s.rng_state = rng.state;
     }
-    finish_paths_wave(sc, rp, film, sample_out, sample_base, i < n_in && !alive, s.lane, s.res, (s.flags & PF_VALID) != 0);
-    // ---- compaction: ballot + popcount inside the wave, one queue atomic per workgroup
-    const unsigned long long m = __ballot(alive);
-    const uint32_t wcount = (uint32_t) __popcll(m);
-    const uint32_t wprefix = (uint32_t) __popcll(m & ((1ull << lane_in_wave) - 1ull));
-    if (lane_in_wave == 0) s_wave_count[wave] = wcount;
-    // wave-level reduction of the shadow-ray counter
+    retire_and_compact<LRT_BLOCK>(sc, rp, had_path, alive, s, film, sample_out, sample_base, qout, cap, cnt, s_wc_m, s_wc_s, s_base);
     for (int off = 32; off > 0; off >>= 1) n_shadow += __shfl_down(n_shadow, off);
-    __syncthreads();
-    if (lane_in_wave == 0 && n_shadow) atomicAdd(&s_shadow, n_shadow);
-    if (tid == 0) {
-        uint32_t total = 0;
-        for (int w = 0; w < LRT_BLOCK / 64; ++w) total += s_wave_count[w];
-        s_base = total ? atomicAdd(&cnt->n_out, total) : 0u;
-    }
-    __syncthreads();
-    if (alive) {
-        uint32_t slot = s_base + wprefix;
-        for (uint32_t w = 0; w < wave; ++w) slot += s_wave_count[w];
-        store_state(qout, slot, s);
-    }
-    if (tid == 0 && s_shadow) atomicAdd(&cnt->n_shadow, (unsigned long long) s_shadow);
+    if ((tid & 63u) == 0 && n_shadow) atomicAdd(&cnt->n_shadow, (unsigned long long) n_shadow);
 }
 
 // Persistent variant for scenes whose BVH fits in LDS: one 1024-thread workgroup per CU copies the scene image into
-// LDS once, then pulls 1024-path tiles from a ticket counter until the in-queue is drained.
-template <int INTEGRATOR>
+// LDS once, then pulls tiles from a ticket counter until both regions of the in-queue are drained.
+template <int INTEGRATOR, int LRT_LDS_BLOCK>
 __global__ void __launch_bounds__(LRT_LDS_BLOCK)
-k_iterate_lds(DScene sc, DRenderParams rp, DLdsInfo li, DPathStreams qin, DPathStreams qout, DCounters *__restrict__ cnt, uint32_t n_in,
-              float *__restrict__ film, float *__restrict__ sample_out, uint64_t sample_base) {
+k_iterate_lds(DScene sc, DRenderParams rp, DLdsInfo li, DPathStreams qin, DPathStreams qout, DCounters *__restrict__ cnt,
+              uint32_t n_m, uint32_t n_s, uint32_t cap, float *__restrict__ film, float *__restrict__ sample_out, uint64_t sample_base) {
     extern __shared__ __align__(16) unsigned char smem[];
-    __shared__ uint32_t s_wave_count[LRT_LDS_BLOCK / 64];
-    __shared__ uint32_t s_base, s_tile;
-    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane_in_wave = tid & 63u;
+    __shared__ uint32_t s_wc_m[LRT_LDS_BLOCK / 64], s_wc_s[LRT_LDS_BLOCK / 64], s_base[2];
+    __shared__ uint32_t s_tile;
+    const uint32_t tid = threadIdx.x, lane_in_wave = tid & 63u;
     {
         const uint4 *src = li.blob; uint4 *dst = reinterpret_cast<uint4 *>(smem);
         for (uint32_t k = tid; k < li.blob_bytes / 16u; k += LRT_LDS_BLOCK) dst[k] = src[k];
@@ -549,40 +586,26 @@ k_iterate_lds(DScene sc, DRenderParams rp, DLdsInfo li, DPathStreams qin, DPathS
     L.nodes = reinterpret_cast<const float4 *>(smem + li.nodes_off); L.verts = reinterpret_cast<const float4 *>(smem + li.verts_off);
     L.tris = reinterpret_cast<const uint2 *>(smem + li.tris_off); L.slot_prim = li.slot_prim;
     L.n_faces = sc.n_faces; L.root_is_leaf = (uint32_t) sc.root_is_leaf; L.root_first = sc.root_leaf_first; L.root_count = sc.root_leaf_count;
-    const LdsTracer tr{ L, reinterpret_cast<uint16_t *>(smem + li.stack_off) + tid };
+    const LdsTracer<LRT_LDS_BLOCK> tr{ L, reinterpret_cast<uint16_t *>(smem + li.stack_off) + tid };
+    const uint32_t n_tiles = (n_m + LRT_LDS_BLOCK - 1) / LRT_LDS_BLOCK + (n_s + LRT_LDS_BLOCK - 1) / LRT_LDS_BLOCK;
     uint32_t n_shadow = 0;
     __syncthreads();
     for (;;) {
         if (tid == 0) s_tile = atomicAdd(&cnt->tile, 1u);
         __syncthreads();
         const uint32_t tile = s_tile;
-        if ((uint64_t) tile * LRT_LDS_BLOCK >= n_in) break;
-        const uint32_t i = tile * LRT_LDS_BLOCK + tid;
+        if (tile >= n_tiles) break;
+        bool had_path; const uint32_t i = queue_index(tile, tid, LRT_LDS_BLOCK, n_m, n_s, cap, &had_path);
         bool alive = false;
-        PathState s;
-        if (i < n_in) {
+        PathState s; s.flags = 0; s.lane = 0; s.res = V3(0.f);
+        if (had_path) {
             load_state(qin, i, s);
             PCG32 rng; rng.state = s.rng_state; rng.inc = lane_rng_inc(rp.seed_value, s.lane);
             if (INTEGRATOR == LRT_INTEGRATOR_PATH) alive = path_iteration(sc, rp, s, rng, tr, n_shadow);
             else alive = volpath_iteration(sc, rp, s, rng, tr, n_shadow);
             s.rng_state = rng.state;
         }
-        finish_paths_wave(sc, rp, film, sample_out, sample_base, i < n_in && !alive, s.lane, s.res, (s.flags & PF_VALID) != 0);
-        const unsigned long long m = __ballot(alive);
-        const uint32_t wprefix = (uint32_t) __popcll(m & ((1ull << lane_in_wave) - 1ull));
-        if (lane_in_wave == 0) s_wave_count[wave] = (uint32_t) __popcll(m);
-        __syncthreads();
-        if (tid == 0) {
-            uint32_t total = 0;
-            for (int w = 0; w < LRT_LDS_BLOCK / 64; ++w) total += s_wave_count[w];
-            s_base = total ? atomicAdd(&cnt->n_out, total) : 0u;
-        }
-        __syncthreads();
-        if (alive) {
-            uint32_t slot = s_base + wprefix;
-            for (uint32_t w = 0; w < wave; ++w) slot += s_wave_count[w];
-            store_state(qout, slot, s);
-        }
+        retire_and_compact<LRT_LDS_BLOCK>(sc, rp, had_path, alive, s, film, sample_out, sample_base, qout, cap, cnt, s_wc_m, s_wc_s, s_base);
     }
     for (int off = 32; off > 0; off >>= 1) n_shadow += __shfl_down(n_shadow, off);
     if (lane_in_wave == 0 && n_shadow) atomicAdd(&cnt->n_shadow, (unsigned long long) n_shadow);
