@@ -203,6 +203,28 @@ DeviceScene *device_scene_create(const lrt_scene_desc &d, int device) {
             D->use_lds = true;
         }
     }
+    // ---- conservative distance field (scenes with participating media: short free-flight segments deep inside a
+    // volume are proven surface-free with one lookup instead of a BVH traversal)
+    sc.grid = DDistGrid{};
+    if (d.n_media > 0 && d.n_faces > 0 && d.n_faces <= (1u << 17) && !getenv("LRT_NO_DIST_GRID")) {
+        float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
+        for (uint32_t f = 0; f < 3 * d.n_faces; ++f) for (int a = 0; a < 3; ++a) { float v = d.positions[3 * (size_t) d.faces[f] + a]; lo[a] = std::min(lo[a], v); hi[a] = std::max(hi[a], v); }
+        const float ext = std::max(hi[0] - lo[0], std::max(hi[1] - lo[1], hi[2] - lo[2]));
+        const int res = getenv("LRT_DIST_GRID_RES") ? std::max(8, std::min(256, atoi(getenv("LRT_DIST_GRID_RES")))) : (d.n_faces <= (1u << 14) ? 128 : 64);
+        if (ext > 0.f && std::isfinite(ext)) {
+            DDistGrid g{};
+            g.cell = ext / (float) res; g.inv_cell = 1.f / g.cell;
+            for (int a = 0; a < 3; ++a) { g.lo[a] = lo[a]; g.n[a] = std::max(1, std::min(res, (int) std::ceil((hi[a] - lo[a]) / g.cell))); }
+            const size_t n_cells = (size_t) g.n[0] * g.n[1] * g.n[2];
+            float *buf = nullptr; HIP_CHECK(hipMalloc((void **) &buf, n_cells * sizeof(float))); D->track(buf);
+            float diag = std::sqrt((hi[0] - lo[0]) * (hi[0] - lo[0]) + (hi[1] - lo[1]) * (hi[1] - lo[1]) + (hi[2] - lo[2]) * (hi[2] - lo[2]));
+            float amax = 0.f; for (int a = 0; a < 3; ++a) amax = std::max(amax, std::max(std::fabs(lo[a]), std::fabs(hi[a])));
+            const float abs_margin = 1e-4f * diag + 1e-5f * amax;          // >> f32 rounding of positions and of the field itself
+            k_build_dist_grid<<<(uint32_t) ((n_cells + LRT_BLOCK - 1) / LRT_BLOCK), LRT_BLOCK, 0, st>>>(sc.tris, (uint32_t) (bvh.tris.size() / 12), g, buf, abs_margin);
+            HIP_CHECK(hipGetLastError());
+            g.d = buf; g.enabled = 1; sc.grid = g;
+        }
+    }
     // ---- geometry attributes
     sc.positions = D->track(dev_upload(d.positions, 3 * (size_t) d.n_vertices, st));
     sc.normals = D->track(dev_upload(d.normals, 3 * (size_t) d.n_vertices, st));
@@ -437,7 +459,7 @@ static void run_wavefront(DeviceScene *D, const lrt_scene_desc &d, const Resolve
     hipStream_t st = D->stream;
     DRenderParams rp = make_params(d, O, n_lanes);
     const uint32_t chunk = (uint32_t) std::min<uint64_t>(n_lanes, 1u << 23);
-    ensure_workspace(D, std::max<uint32_t>(chunk, 1));
+    ensure_workspace(D, 2 * std::max<uint32_t>(chunk, 1));
     const bool prb = O.integrator == LRT_INTEGRATOR_PRBVOLPATH;
     if (prb) ensure_prb_workspace(D, std::max<uint32_t>(chunk, 1));
     HIP_CHECK(hipMemsetAsync(D->counters, 0, sizeof(DCounters), st));
@@ -461,38 +483,40 @@ static void run_wavefront(DeviceScene *D, const lrt_scene_desc &d, const Resolve
     }
     // Streaming regeneration: every launch first tops the in-queue up with fresh camera rays (back region), so launches stay
     // full until the lanes run out; the two-region queue keeps in-medium and surface paths in separate tiles.
-    const uint32_t cap = D->capacity;
-    uint64_t next = 0; uint32_t n_m = 0, n_s = 0; int cur = 0;
-    while (next < n_lanes || n_m + n_s > 0) {
-        const uint32_t fresh = (uint32_t) std::min<uint64_t>(n_lanes - next, chunk - (n_m + n_s));
+    const uint32_t cap = D->capacity;                      // = 2 * chunk: see queue_index() in kernels.h
+    uint64_t next = 0; uint32_t n_a = 0, n_c = 0, n_b = 0; int cur = 0;
+    while (next < n_lanes || n_a + n_c + n_b > 0) {
+        const uint32_t fresh = (uint32_t) std::min<uint64_t>(n_lanes - next, chunk - (n_a + n_c + n_b));
         if (fresh) {
-            k_raygen<<<(fresh + LRT_BLOCK - 1) / LRT_BLOCK, LRT_BLOCK, 0, st>>>(D->sc, rp, D->q[cur], pixel_list, lane_begin + next, fresh, n_s, cap);
-            next += fresh; n_s += fresh;
+            k_raygen<<<(fresh + LRT_BLOCK - 1) / LRT_BLOCK, LRT_BLOCK, 0, st>>>(D->sc, rp, D->q[cur], pixel_list, lane_begin + next, fresh, n_b, cap);
+            next += fresh; n_b += fresh;
         }
-        HIP_CHECK(hipMemsetAsync(&D->counters->n_out, 0, 3 * sizeof(uint32_t), st));      // n_out, tile ticket, n_out_s
+        HIP_CHECK(hipMemsetAsync(D->counters, 0, 4 * sizeof(uint32_t), st));      // the three region counters and the tile ticket
         hipEvent_t a = get_event(D, log.ev++), b = get_event(D, log.ev++);
         HIP_CHECK(hipEventRecord(a, st));
         const bool isp = O.integrator == LRT_INTEGRATOR_PATH;
+        const uint32_t n_all = n_a + n_c + n_b;
         if (D->use_lds) {
             const uint32_t B = (uint32_t) D->lds_block;
-            const uint32_t g = std::min<uint32_t>((uint32_t) D->n_cus, (n_m + B - 1) / B + (n_s + B - 1) / B);
-            #define LRT_LAUNCH_LDS(I, BS) k_iterate_lds<I, BS><<<g, BS, D->lds.total_bytes, st>>>(D->sc, rp, D->lds, D->q[cur], D->q[cur ^ 1], D->counters, n_m, n_s, cap, film, sample_out, lane_begin)
+            const uint32_t g = std::min<uint32_t>((uint32_t) D->n_cus, (n_a + B - 1) / B + (n_c + B - 1) / B + (n_b + B - 1) / B);
+            #define LRT_LAUNCH_LDS(I, BS) k_iterate_lds<I, BS><<<g, BS, D->lds.total_bytes, st>>>(D->sc, rp, D->lds, D->q[cur], D->q[cur ^ 1], D->counters, n_a, n_c, n_b, cap, film, sample_out, lane_begin)
             if (B == 512) { if (isp) LRT_LAUNCH_LDS(LRT_INTEGRATOR_PATH, 512); else LRT_LAUNCH_LDS(LRT_INTEGRATOR_VOLPATH, 512); }
             else { if (isp) LRT_LAUNCH_LDS(LRT_INTEGRATOR_PATH, 1024); else LRT_LAUNCH_LDS(LRT_INTEGRATOR_VOLPATH, 1024); }
             #undef LRT_LAUNCH_LDS
         } else {
-            const uint32_t grid = (n_m + LRT_BLOCK - 1) / LRT_BLOCK + (n_s + LRT_BLOCK - 1) / LRT_BLOCK;
-            if (isp) k_iterate<LRT_INTEGRATOR_PATH><<<grid, LRT_BLOCK, 0, st>>>(D->sc, rp, D->q[cur], D->q[cur ^ 1], D->counters, n_m, n_s, cap, film, sample_out, lane_begin);
-            else k_iterate<LRT_INTEGRATOR_VOLPATH><<<grid, LRT_BLOCK, 0, st>>>(D->sc, rp, D->q[cur], D->q[cur ^ 1], D->counters, n_m, n_s, cap, film, sample_out, lane_begin);
+            const uint32_t grid = (n_a + LRT_BLOCK - 1) / LRT_BLOCK + (n_c + LRT_BLOCK - 1) / LRT_BLOCK + (n_b + LRT_BLOCK - 1) / LRT_BLOCK;
+            if (isp) k_iterate<LRT_INTEGRATOR_PATH><<<grid, LRT_BLOCK, 0, st>>>(D->sc, rp, D->q[cur], D->q[cur ^ 1], D->counters, n_a, n_c, n_b, cap, film, sample_out, lane_begin);
+            else k_iterate<LRT_INTEGRATOR_VOLPATH><<<grid, LRT_BLOCK, 0, st>>>(D->sc, rp, D->q[cur], D->q[cur ^ 1], D->counters, n_a, n_c, n_b, cap, film, sample_out, lane_begin);
         }
         HIP_CHECK(hipEventRecord(b, st));
-        log.launches.emplace_back(a, b); log.sizes.push_back(n_m + n_s);
+        log.launches.emplace_back(a, b); log.sizes.push_back(n_all);
         HIP_CHECK(hipMemcpyAsync(D->h_counters, D->counters, sizeof(DCounters), hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));
-        if (count_iter) log.n_iter += n_m + n_s;
-        n_m = D->h_counters->n_out; n_s = D->h_counters->n_out_s;
+        if (count_iter) log.n_iter += n_all;
+        n_a = D->h_counters->n_out; n_c = D->h_counters->n_out_t; n_b = D->h_counters->n_out_s;
         cur ^= 1;
     }
+    if (!log.launches.empty()) log.n_iter += D->h_counters->n_iter;   // trips retired early by the look-ahead (volpath_iteration)
     finish_stats(D, log, e_begin, e_end, n_lanes, stats);
 }
 

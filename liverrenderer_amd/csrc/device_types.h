@@ -72,6 +72,15 @@ struct DEnv {
     float radiance[3];         // constant emitter
 };
 
+// Conservative distance field over the triangle soup (see dist_grid_lower_bound() in dshade.h): value = distance from
+// the cell centre to the nearest triangle, rounded down.  Lets short in-medium segments prove "no surface within reach"
+// without touching the BVH.  The answer of a ray query never depends on it.
+struct DDistGrid {
+    const float *d;
+    float lo[3]; float cell, inv_cell;
+    int32_t n[3]; int32_t enabled;
+};
+
 struct DScene {
     // acceleration structure
     const float4 *nodes;       // 4 x float4 per BVH2 node (see bvh.h)
@@ -88,6 +97,7 @@ struct DScene {
     int32_t nee_fast_reject, pad0;   // see volpath_iteration(): in-medium NEE can be rejected before sampling the emitter
     uint32_t root_leaf_first, root_leaf_count;
     DCamera cam; DFilm film; DEnv env;
+    DDistGrid grid;
 };
 
 struct DRenderParams {
@@ -117,10 +127,11 @@ struct DPathStreams {
 #define PF_CHANNEL_SHIFT 24            // 2 bits
 #define PF_SPECULAR     (1u << 26)     // volpath specular_chain / path prev_bsdf_delta
 #define PF_VALID        (1u << 27)
+#define PF_NOHIT        (1u << 28)     // look-ahead proved that the next free-flight segment reaches no surface
 
 struct DCounters {             // device-resident queue / statistics words
-    uint32_t n_in, n_out;      // n_out: survivors that continue inside a medium (front region of the out queue)
-    uint32_t tile, n_out_s;    // tile: work ticket of the persistent kernel; n_out_s: survivors outside media (back region)
+    uint32_t n_out_t, n_out;   // survivors inside a medium: n_out = next segment proven free of surfaces (region A), n_out_t = needs a ray query (region C)
+    uint32_t tile, n_out_s;    // tile: work ticket of the persistent kernel; n_out_s: survivors outside media (region B)
     unsigned long long n_shadow;
     unsigned long long n_iter;
 };

@@ -267,8 +267,9 @@ DEV V3 volpath_sample_emitter(const DScene &sc, PCG32 &rng, V3 ref_p, V3 ref_n, 
 // One trip of volpath's while_loop (src/integrators/volpath.cpp:170-391).
 // Returns true when the path survives.
 template <typename TR>
-DEV bool volpath_iteration(const DScene &sc, const DRenderParams &rp, PathState &s, PCG32 &rng, const TR &tr, uint32_t &n_shadow) {
+DEV bool volpath_iteration(const DScene &sc, const DRenderParams &rp, PathState &s, PCG32 &rng, const TR &tr, uint32_t &n_shadow, uint32_t &n_extra) {
     uint32_t depth = s.flags & PF_DEPTH_MASK;
+    const bool proven_empty = (s.flags & PF_NOHIT) != 0;
     int medium = (int) ((s.flags & PF_MEDIUM_MASK) >> PF_MEDIUM_SHIFT) - 1;
     const uint32_t channel = (s.flags >> PF_CHANNEL_SHIFT) & 3u;
     bool specular_chain = (s.flags & PF_SPECULAR) != 0, valid_ray = (s.flags & PF_VALID) != 0;
@@ -298,7 +299,7 @@ DEV bool volpath_iteration(const DScene &sc, const DRenderParams &rp, PathState 
         const DMedium M = sc.media[medium];
         mei = medium_sample_interaction(M, ray, rng.next(), channel);
         if (mei.valid()) ray.maxt = mei.t;
-        { Hit h = tr.closest(ray); si = compute_si(sc, ray, h); }
+        if (!proven_empty) { Hit h = tr.closest(ray); si = compute_si(sc, ray, h); }   // else: no surface within mei.t (look-ahead of the previous trip)
         if (si.t < mei.t) mei.t = kInf;
         if (M.has_spectral_extinction) {
             float t = fmin_(mei.t, si.t) - mei.mint;
@@ -417,7 +418,26 @@ DEV bool volpath_iteration(const DScene &sc, const DRenderParams &rp, PathState 
         if (is_medium_transition(sd)) medium = target_medium(sd, ray.d, si.n);
     }
     active = active && (active_surface || active_medium);
+    // ---- look-ahead into the next trip (exact: same draws on a copy of the generator).  (1) A path the next trip's
+    // termination test (volpath.cpp:190-203) would stop is retired now; that trip is counted in n_extra.  (2) For a path
+    // inside a medium the next free-flight distance is known, so the distance field may already prove that the segment
+    // reaches no surface: such paths are queued separately and skip the ray query.
+    uint32_t nohit = 0;
+    if (active) {
+        PCG32 pk = rng;
+        bool a2 = any_nonzero(throughput);
+        float q2 = fmin_(max3(throughput) * sqr(eta), .95f);
+        if (a2) { float u = pk.next(); a2 = (u < q2) || !(depth > (uint32_t) rp.rr_depth); }
+        a2 = a2 && depth < max_depth;
+        if (!a2) { active = false; n_extra += 1; }
+        else if (medium >= 0 && sc.grid.enabled) {
+            const DMedium M = sc.media[medium];
+            MI m2 = medium_sample_interaction(M, ray, pk.next(), channel);
+            if (m2.valid() && segment_proven_empty(sc.grid, ray.o, ray.d, m2.t)) nohit = PF_NOHIT;
+        }
+    }
     commit();
+    s.flags |= nohit;
     return active;
 }
 
@@ -506,14 +526,19 @@ DEV bool path_iteration(const DScene &sc, const DRenderParams &rp, PathState &s,
     return active;
 }
 
-// ---- queues.  A queue (one set of path streams of `cap` records) holds two regions: paths that are inside a medium grow
-// from the front ([0, n_m)), all other paths (camera rays, paths outside media) from the back (record cap-1-j, j in [0, n_s)).
-// Tiles never mix the two populations, which keeps a wave's lanes on the same branch of the loop body.
-DEV uint32_t queue_index(uint32_t tile, uint32_t tid, uint32_t B, uint32_t n_m, uint32_t n_s, uint32_t cap, bool *valid) {
-    const uint32_t tiles_m = (n_m + B - 1) / B;
-    if (tile < tiles_m) { uint32_t i = tile * B + tid; *valid = i < n_m; return i; }
-    uint32_t j = (tile - tiles_m) * B + tid; *valid = j < n_s; return cap - 1u - j;
+// ---- queues.  A queue (one set of path streams of `cap` records, cap = 2 x the paths in flight) holds three regions:
+//   A  [0, n_a)                 in-medium paths whose next segment is proven free of surfaces (no ray query)
+//   C  [cap/2, cap/2 + n_c)     in-medium paths that need their ray query
+//   B  cap-1-j, j in [0, n_b)   paths outside media (camera rays, surface bounces)
+// n_a + n_b + n_c <= cap/2, so the regions never collide.  Tiles never mix populations, which keeps a wave's lanes on
+// the same branch of the loop body.
+DEV uint32_t queue_index(uint32_t tile, uint32_t tid, uint32_t B, uint32_t n_a, uint32_t n_c, uint32_t n_b, uint32_t cap, bool *valid) {
+    const uint32_t tiles_a = (n_a + B - 1) / B, tiles_c = (n_c + B - 1) / B;
+    if (tile < tiles_a) { uint32_t i = tile * B + tid; *valid = i < n_a; return i; }
+    if (tile < tiles_a + tiles_c) { uint32_t i = (tile - tiles_a) * B + tid; *valid = i < n_c; return (cap >> 1) + i; }
+    uint32_t j = (tile - tiles_a - tiles_c) * B + tid; *valid = j < n_b; return cap - 1u - j;
 }
+DEV uint32_t queue_tiles(uint32_t B, uint32_t n_a, uint32_t n_c, uint32_t n_b) { return (n_a + B - 1) / B + (n_c + B - 1) / B + (n_b + B - 1) / B; }
 
 // Retires finished paths into the film and appends survivors to the out queue: __ballot + popcount prefix inside the
 // wave, one atomic per region and workgroup.  Called by every thread of the workgroup (two barriers inside).
@@ -521,51 +546,53 @@ template <int B>
 DEV void retire_and_compact(const DScene &sc, const DRenderParams &rp, bool had_path, bool alive, const PathState &s,
                             float *__restrict__ film, float *__restrict__ sample_out, uint64_t sample_base,
                             const DPathStreams &qout, uint32_t cap, DCounters *__restrict__ cnt,
-                            uint32_t *s_wc_m, uint32_t *s_wc_s, uint32_t *s_base /* [2] */) {
+                            uint32_t (*s_wc)[B / 64] /* [3] */, uint32_t *s_base /* [3] */) {
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane_in_wave = tid & 63u;
     finish_paths_wave(sc, rp, film, sample_out, sample_base, had_path && !alive, s.lane, s.res, (s.flags & PF_VALID) != 0);
-    const bool in_medium = (s.flags & PF_MEDIUM_MASK) != 0;
-    const unsigned long long mm = __ballot(alive && in_medium), ms = __ballot(alive && !in_medium);
+    const int region = !(s.flags & PF_MEDIUM_MASK) ? 2 : ((s.flags & PF_NOHIT) ? 0 : 1);
+    const unsigned long long m0 = __ballot(alive && region == 0), m1 = __ballot(alive && region == 1), m2 = __ballot(alive && region == 2);
     const unsigned long long below = (1ull << lane_in_wave) - 1ull;
-    if (lane_in_wave == 0) { s_wc_m[wave] = (uint32_t) __popcll(mm); s_wc_s[wave] = (uint32_t) __popcll(ms); }
+    if (lane_in_wave == 0) { s_wc[0][wave] = (uint32_t) __popcll(m0); s_wc[1][wave] = (uint32_t) __popcll(m1); s_wc[2][wave] = (uint32_t) __popcll(m2); }
     __syncthreads();
-    if (tid == 0) {
-        uint32_t tm = 0, ts = 0;
-        for (int w = 0; w < B / 64; ++w) { tm += s_wc_m[w]; ts += s_wc_s[w]; }
-        s_base[0] = tm ? atomicAdd(&cnt->n_out, tm) : 0u;
-        s_base[1] = ts ? atomicAdd(&cnt->n_out_s, ts) : 0u;
+    if (tid < 3) {
+        uint32_t t = 0;
+        for (int w = 0; w < B / 64; ++w) t += s_wc[tid][w];
+        uint32_t *dst = tid == 0 ? &cnt->n_out : (tid == 1 ? &cnt->n_out_t : &cnt->n_out_s);
+        s_base[tid] = t ? atomicAdd(dst, t) : 0u;
     }
     __syncthreads();
     if (alive) {
-        uint32_t slot = in_medium ? s_base[0] + (uint32_t) __popcll(mm & below) : s_base[1] + (uint32_t) __popcll(ms & below);
-        for (uint32_t w = 0; w < wave; ++w) slot += in_medium ? s_wc_m[w] : s_wc_s[w];
-        store_state(qout, in_medium ? slot : cap - 1u - slot, s);
+        const unsigned long long mine = region == 0 ? m0 : (region == 1 ? m1 : m2);
+        uint32_t slot = s_base[region] + (uint32_t) __popcll(mine & below);
+        for (uint32_t w = 0; w < wave; ++w) slot += s_wc[region][w];
+        store_state(qout, region == 0 ? slot : (region == 1 ? (cap >> 1) + slot : cap - 1u - slot), s);
     }
 }
 
 // Grid-launched variant: BVH in global memory (any scene size), one 256-path tile per workgroup.
 template <int INTEGRATOR>
 __global__ void __launch_bounds__(LRT_BLOCK)
-k_iterate(DScene sc, DRenderParams rp, DPathStreams qin, DPathStreams qout, DCounters *__restrict__ cnt, uint32_t n_m, uint32_t n_s, uint32_t cap,
+k_iterate(DScene sc, DRenderParams rp, DPathStreams qin, DPathStreams qout, DCounters *__restrict__ cnt, uint32_t n_a, uint32_t n_c, uint32_t n_b, uint32_t cap,
           float *__restrict__ film, float *__restrict__ sample_out, uint64_t sample_base) {
     __shared__ int s_stack[LRT_STACK * LRT_BLOCK];
-    __shared__ uint32_t s_wc_m[LRT_BLOCK / 64], s_wc_s[LRT_BLOCK / 64], s_base[2];
+    __shared__ uint32_t s_wc[3][LRT_BLOCK / 64], s_base[3];
     const uint32_t tid = threadIdx.x;
-    bool had_path; const uint32_t i = queue_index(blockIdx.x, tid, LRT_BLOCK, n_m, n_s, cap, &had_path);
+    bool had_path; const uint32_t i = queue_index(blockIdx.x, tid, LRT_BLOCK, n_a, n_c, n_b, cap, &had_path);
     bool alive = false;
     PathState s; s.flags = 0; s.lane = 0; s.res = V3(0.f);
-    uint32_t n_shadow = 0;
+    uint32_t n_shadow = 0, n_extra = 0;
     if (had_path) {
         load_state(qin, i, s);
         PCG32 rng; rng.state = s.rng_state; rng.inc = lane_rng_inc(rp.seed_value, s.lane);
         const GlobalTracer tr{ sc, s_stack + tid };
         if (INTEGRATOR == LRT_INTEGRATOR_PATH) alive = path_iteration(sc, rp, s, rng, tr, n_shadow);
-        else alive = volpath_iteration(sc, rp, s, rng, tr, n_shadow);
+        else alive = volpath_iteration(sc, rp, s, rng, tr, n_shadow, n_extra);
         s.rng_state = rng.state;
     }
-    retire_and_compact<LRT_BLOCK>(sc, rp, had_path, alive, s, film, sample_out, sample_base, qout, cap, cnt, s_wc_m, s_wc_s, s_base);
-    for (int off = 32; off > 0; off >>= 1) n_shadow += __shfl_down(n_shadow, off);
+    retire_and_compact<LRT_BLOCK>(sc, rp, had_path, alive, s, film, sample_out, sample_base, qout, cap, cnt, s_wc, s_base);
+    for (int off = 32; off > 0; off >>= 1) { n_shadow += __shfl_down(n_shadow, off); n_extra += __shfl_down(n_extra, off); }
     if ((tid & 63u) == 0 && n_shadow) atomicAdd(&cnt->n_shadow, (unsigned long long) n_shadow);
+    if ((tid & 63u) == 0 && n_extra) atomicAdd(&cnt->n_iter, (unsigned long long) n_extra);
 }
 
 // Persistent variant for scenes whose BVH fits in LDS: one 1024-thread workgroup per CU copies the scene image into
@@ -573,9 +600,9 @@ k_iterate(DScene sc, DRenderParams rp, DPathStreams qin, DPathStreams qout, DCou
 template <int INTEGRATOR, int LRT_LDS_BLOCK>
 __global__ void __launch_bounds__(LRT_LDS_BLOCK)
 k_iterate_lds(DScene sc, DRenderParams rp, DLdsInfo li, DPathStreams qin, DPathStreams qout, DCounters *__restrict__ cnt,
-              uint32_t n_m, uint32_t n_s, uint32_t cap, float *__restrict__ film, float *__restrict__ sample_out, uint64_t sample_base) {
+              uint32_t n_a, uint32_t n_c, uint32_t n_b, uint32_t cap, float *__restrict__ film, float *__restrict__ sample_out, uint64_t sample_base) {
     extern __shared__ __align__(16) unsigned char smem[];
-    __shared__ uint32_t s_wc_m[LRT_LDS_BLOCK / 64], s_wc_s[LRT_LDS_BLOCK / 64], s_base[2];
+    __shared__ uint32_t s_wc[3][LRT_LDS_BLOCK / 64], s_base[3];
     __shared__ uint32_t s_tile;
     const uint32_t tid = threadIdx.x, lane_in_wave = tid & 63u;
     {
@@ -587,28 +614,70 @@ k_iterate_lds(DScene sc, DRenderParams rp, DLdsInfo li, DPathStreams qin, DPathS
     L.tris = reinterpret_cast<const uint2 *>(smem + li.tris_off); L.slot_prim = li.slot_prim;
     L.n_faces = sc.n_faces; L.root_is_leaf = (uint32_t) sc.root_is_leaf; L.root_first = sc.root_leaf_first; L.root_count = sc.root_leaf_count;
     const LdsTracer<LRT_LDS_BLOCK> tr{ L, reinterpret_cast<uint16_t *>(smem + li.stack_off) + tid };
-    const uint32_t n_tiles = (n_m + LRT_LDS_BLOCK - 1) / LRT_LDS_BLOCK + (n_s + LRT_LDS_BLOCK - 1) / LRT_LDS_BLOCK;
-    uint32_t n_shadow = 0;
+    const uint32_t n_tiles = queue_tiles(LRT_LDS_BLOCK, n_a, n_c, n_b);
+    uint32_t n_shadow = 0, n_extra = 0;
     __syncthreads();
     for (;;) {
         if (tid == 0) s_tile = atomicAdd(&cnt->tile, 1u);
         __syncthreads();
         const uint32_t tile = s_tile;
         if (tile >= n_tiles) break;
-        bool had_path; const uint32_t i = queue_index(tile, tid, LRT_LDS_BLOCK, n_m, n_s, cap, &had_path);
+        bool had_path; const uint32_t i = queue_index(tile, tid, LRT_LDS_BLOCK, n_a, n_c, n_b, cap, &had_path);
         bool alive = false;
         PathState s; s.flags = 0; s.lane = 0; s.res = V3(0.f);
         if (had_path) {
             load_state(qin, i, s);
             PCG32 rng; rng.state = s.rng_state; rng.inc = lane_rng_inc(rp.seed_value, s.lane);
             if (INTEGRATOR == LRT_INTEGRATOR_PATH) alive = path_iteration(sc, rp, s, rng, tr, n_shadow);
-            else alive = volpath_iteration(sc, rp, s, rng, tr, n_shadow);
+            else alive = volpath_iteration(sc, rp, s, rng, tr, n_shadow, n_extra);
             s.rng_state = rng.state;
         }
-        retire_and_compact<LRT_LDS_BLOCK>(sc, rp, had_path, alive, s, film, sample_out, sample_base, qout, cap, cnt, s_wc_m, s_wc_s, s_base);
+        retire_and_compact<LRT_LDS_BLOCK>(sc, rp, had_path, alive, s, film, sample_out, sample_base, qout, cap, cnt, s_wc, s_base);
     }
-    for (int off = 32; off > 0; off >>= 1) n_shadow += __shfl_down(n_shadow, off);
+    for (int off = 32; off > 0; off >>= 1) { n_shadow += __shfl_down(n_shadow, off); n_extra += __shfl_down(n_extra, off); }
     if (lane_in_wave == 0 && n_shadow) atomicAdd(&cnt->n_shadow, (unsigned long long) n_shadow);
+    if (lane_in_wave == 0 && n_extra) atomicAdd(&cnt->n_iter, (unsigned long long) n_extra);
+}
+
+// Distance field build (scene upload): one thread per cell, exact point-triangle distance (closest-feature regions of
+// the triangle: vertices, edges, face) against every triangle slot of the BVH image (p0 | e1 | e2).
+DEV float point_triangle_dist2(V3 p, V3 a, V3 ab, V3 ac) {
+    V3 ap = p - a;
+    float d1 = dot(ab, ap), d2 = dot(ac, ap);
+    if (d1 <= 0.f && d2 <= 0.f) return dot(ap, ap);
+    V3 bp = ap - ab;
+    float d3 = dot(ab, bp), d4 = dot(ac, bp);
+    if (d3 >= 0.f && d4 <= d3) return dot(bp, bp);
+    float vc = d1 * d4 - d3 * d2;
+    if (vc <= 0.f && d1 >= 0.f && d3 <= 0.f) { V3 r = ap - ab * (d1 / (d1 - d3)); return dot(r, r); }
+    V3 cp = ap - ac;
+    float d5 = dot(ab, cp), d6 = dot(ac, cp);
+    if (d6 >= 0.f && d5 <= d6) return dot(cp, cp);
+    float vb = d5 * d2 - d1 * d6;
+    if (vb <= 0.f && d2 >= 0.f && d6 <= 0.f) { V3 r = ap - ac * (d2 / (d2 - d6)); return dot(r, r); }
+    float va = d3 * d6 - d5 * d4;
+    if (va <= 0.f && (d4 - d3) >= 0.f && (d5 - d6) >= 0.f) { V3 r = bp - (ac - ab) * ((d4 - d3) / ((d4 - d3) + (d5 - d6))); return dot(r, r); }
+    float denom = 1.f / (va + vb + vc);
+    V3 r = ap - ab * (vb * denom) - ac * (vc * denom);
+    return dot(r, r);
+}
+
+__global__ void __launch_bounds__(LRT_BLOCK)
+k_build_dist_grid(const float4 *__restrict__ tris, uint32_t n_slots, DDistGrid g, float *__restrict__ out, float abs_margin) {
+    const size_t n_cells = (size_t) g.n[0] * g.n[1] * g.n[2];
+    const size_t c = (size_t) blockIdx.x * LRT_BLOCK + threadIdx.x;
+    if (c >= n_cells) return;
+    const int ix = (int) (c % g.n[0]), iy = (int) ((c / g.n[0]) % g.n[1]), iz = (int) (c / ((size_t) g.n[0] * g.n[1]));
+    const V3 p(g.lo[0] + ((float) ix + .5f) * g.cell, g.lo[1] + ((float) iy + .5f) * g.cell, g.lo[2] + ((float) iz + .5f) * g.cell);
+    float best = kInf;
+    for (uint32_t sl = 0; sl < n_slots; ++sl) {
+        const float4 a = tris[3 * sl], b = tris[3 * sl + 1], cc = tris[3 * sl + 2];
+        float d2 = point_triangle_dist2(p, V3(a.x, a.y, a.z), V3(b.x, b.y, b.z), V3(cc.x, cc.y, cc.z));
+        if (!(d2 >= 0.f)) d2 = 0.f;                 // degenerate triangle (NaN): be conservative
+        best = fmin_(best, d2);
+    }
+    float d = __builtin_sqrtf(best) * .999f - abs_margin;
+    out[c] = d > 0.f ? d : 0.f;
 }
 
 // src/films/hdrfilm.cpp:306-410
