@@ -87,11 +87,11 @@ def main():
         step(1000 + i)
     fence()
     t0 = time.perf_counter()
-    kern_ms = iters = shadows = launches = 0.0
+    kern_ms = iters = shadows = launches = records = 0.0
     for i in range(a.steps):
         img = step(i)
         st = scene.stats()
-        kern_ms += st["kernel_ms"]; iters += st["n_iter"]; shadows += st["n_shadow"]; launches += st["n_launches"]
+        kern_ms += st["kernel_ms"]; iters += st["n_iter"]; shadows += st["n_shadow"]; launches += st["n_launches"]; records += st["n_records"]
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -101,16 +101,18 @@ def main():
     value = n_samples * a.steps / dt / 1e6
 
     # ---- roofline of the dominant kernel (k_iterate), this rank's launches.  Algorithmic bytes per
-    # launch: every live path record is read once (88 B) and every surviving one written once (88 B);
-    # summed over a render: 88 * (2 * n_iter - n_samples_rank); plus 4*C bytes per pixel of film.
+    # launch: every queued path record is read once (88 B) and every surviving one written once (88 B);
+    # summed over a render: 88 * (2 * n_records - n_samples_rank); plus 4*C bytes per pixel of film.
+    # n_records <= n_iter: loop trips the look-ahead retires early move no record.
     n_rank = st["n_samples"]
-    alg_bytes = STATE_BYTES * (2.0 * iters - n_rank * a.steps) + 4.0 * C * w * h * a.steps / max(world, 1)
+    alg_bytes = STATE_BYTES * (2.0 * records - n_rank * a.steps) + 4.0 * C * w * h * a.steps / max(world, 1)
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                "kernel": "k_iterate<volpath>" if a.integrator != "path" else "k_iterate<path>",
+                "kernel": "lrt::k_iterate_lds<%d, 1024> (lrt::k_iterate<%d> when the BVH does not fit LDS)" % ((0, 0) if a.integrator == "path" else (1, 1)),
                 "launches_per_step": launches / a.steps, "avg_launch_ms": kern_ms / max(launches, 1),
-                "alg_bytes_per_launch": alg_bytes / max(launches, 1), "iterations_per_sample": iters / (n_rank * a.steps)}
+                "alg_bytes_per_launch": alg_bytes / max(launches, 1), "iterations_per_sample": iters / (n_rank * a.steps),
+                "records_per_sample": records / (n_rank * a.steps)}
 
     out = {"metric": "Msamples/s", "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": a.steps,
            "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",

@@ -179,6 +179,8 @@ typedef struct {
     uint64_t n_iter;          /* path-loop iterations executed (all paths)         */
     uint64_t n_shadow;        /* NEE visibility / march ray queries traced         */
     uint64_t n_launches;      /* iteration-kernel launches                         */
+    uint64_t n_records;       /* path records read by those launches (<= n_iter:
+                                 trips retired by look-ahead move no record)        */
     double   kernel_ms;       /* sum of iteration-kernel durations (HIP events)    */
     double   total_ms;        /* whole lrt_render device time (HIP events)         */
 } lrt_render_stats;

@@ -76,7 +76,7 @@ class RenderOpts(C.Structure):
 
 class RenderStats(C.Structure):
     _fields_ = [("n_samples", C.c_uint64), ("n_iter", C.c_uint64), ("n_shadow", C.c_uint64), ("n_launches", C.c_uint64),
-                ("kernel_ms", C.c_double), ("total_ms", C.c_double)]
+                ("n_records", C.c_uint64), ("kernel_ms", C.c_double), ("total_ms", C.c_double)]
 
 
 class ParamGrads(C.Structure):

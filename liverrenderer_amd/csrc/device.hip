@@ -6,6 +6,7 @@
 #include "kernels_prb.h"
 #include "bvh.h"
 #include <cmath>
+#include <array>
 #include <cstring>
 #include <algorithm>
 #include <stdexcept>
@@ -402,11 +403,12 @@ static DRenderParams make_params(const lrt_scene_desc &d, const ResolvedOpts &O,
     DRenderParams rp{};
     rp.integrator = O.integrator; rp.max_depth = O.max_depth; rp.rr_depth = O.rr_depth; rp.hide_emitters = O.hide_emitters;
     rp.spp = O.spp; rp.log2_spp = ((O.spp & (O.spp - 1)) == 0) ? (uint32_t) __builtin_ctz(O.spp) : 0xffffffffu;
+    rp.profile = getenv("LRT_DEBUG_LAUNCH") ? 1u : 0u;
     rp.seed_value = d.sampler_seed + O.seed; rp.tile_rank = O.tile_rank; rp.tile_count = O.tile_count; rp.n_lanes = n_lanes;
     return rp;
 }
 
-struct LaunchLog { std::vector<std::pair<hipEvent_t, hipEvent_t>> launches; std::vector<uint32_t> sizes; size_t ev = 0; uint64_t n_iter = 0; };
+struct LaunchLog { std::vector<std::pair<hipEvent_t, hipEvent_t>> launches; std::vector<uint32_t> sizes; std::vector<std::array<uint32_t, 3>> regions; size_t ev = 0; uint64_t n_iter = 0; };
 
 // Drains one chunk of `n` freshly generated paths sitting in q[0]: launches `iterate(cur, n)` until the queue is empty.
 template <typename Iterate>
@@ -444,12 +446,22 @@ static void finish_stats(DeviceScene *D, LaunchLog &log, hipEvent_t e_begin, hip
     HIP_CHECK(hipStreamSynchronize(st));
     HIP_CHECK(hipGetLastError());
     stats.n_samples = n_lanes; stats.n_iter = log.n_iter; stats.n_shadow = D->h_counters->n_shadow; stats.n_launches = log.launches.size();
+    stats.n_records = 0; for (uint32_t n : log.sizes) stats.n_records += n;
     float ms = 0.f; double ksum = 0.0;
     for (size_t i = 0; i < log.launches.size(); ++i) {
         HIP_CHECK(hipEventElapsedTime(&ms, log.launches[i].first, log.launches[i].second)); ksum += ms;
-        if (getenv("LRT_DEBUG_LAUNCH") && i < 40) fprintf(stderr, "[lrt] launch %zu: n=%u %.3f ms (%.2f Gpath-iter/s)\n", i, log.sizes[i], ms, log.sizes[i] / ms * 1e-6);
+        if (getenv("LRT_DEBUG_LAUNCH") && i < 40) {
+            fprintf(stderr, "[lrt] launch %zu: n=%u %.3f ms (%.2f Gpath-iter/s)", i, log.sizes[i], ms, log.sizes[i] / ms * 1e-6);
+            if (i < log.regions.size()) fprintf(stderr, "  proven-free %u  query %u  surface %u", log.regions[i][0], log.regions[i][1], log.regions[i][2]);
+            fprintf(stderr, "\n");
+        }
     }
     stats.kernel_ms = ksum;
+    if (getenv("LRT_DEBUG_LAUNCH")) for (int r = 0; r < 3; ++r) {
+        unsigned long long host_tiles = 0; for (auto &g : log.regions) host_tiles += (g[r] + 1023) / 1024;
+        fprintf(stderr, "[lrt] region %d: host count %llu tiles\n", r, host_tiles);
+        fprintf(stderr, "[lrt] region %d: %llu tiles, %.1f ticks/tile (100 MHz wall clock)\n", r, D->h_counters->prof_tiles[r], D->h_counters->prof_tiles[r] ? (double) D->h_counters->prof_cycles[r] / D->h_counters->prof_tiles[r] : 0.0);
+    }
     HIP_CHECK(hipEventElapsedTime(&ms, e_begin, e_end)); stats.total_ms = ms;
 }
 
@@ -509,7 +521,7 @@ static void run_wavefront(DeviceScene *D, const lrt_scene_desc &d, const Resolve
             else k_iterate<LRT_INTEGRATOR_VOLPATH><<<grid, LRT_BLOCK, 0, st>>>(D->sc, rp, D->q[cur], D->q[cur ^ 1], D->counters, n_a, n_c, n_b, cap, film, sample_out, lane_begin);
         }
         HIP_CHECK(hipEventRecord(b, st));
-        log.launches.emplace_back(a, b); log.sizes.push_back(n_all);
+        log.launches.emplace_back(a, b); log.sizes.push_back(n_all); log.regions.push_back({ n_a, n_c, n_b });
         HIP_CHECK(hipMemcpyAsync(D->h_counters, D->counters, sizeof(DCounters), hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));
         if (count_iter) log.n_iter += n_all;

@@ -105,7 +105,7 @@ struct DRenderParams {
     uint32_t spp, log2_spp;    // log2_spp = 0xffffffff when spp is not a power of two
     uint32_t seed_value;       // sampler base seed + render seed
     uint32_t tile_rank, tile_count;
-    uint32_t tiles_x, tiles_y, pad;
+    uint32_t tiles_x, tiles_y, profile;   // profile: per-region tile timing into DCounters (developer aid, LRT_DEBUG_LAUNCH)
     uint64_t n_lanes;          // lanes this rank renders
 };
 
@@ -134,6 +134,7 @@ struct DCounters {             // device-resident queue / statistics words
     uint32_t tile, n_out_s;    // tile: work ticket of the persistent kernel; n_out_s: survivors outside media (region B)
     unsigned long long n_shadow;
     unsigned long long n_iter;
+    unsigned long long prof_cycles[3], prof_tiles[3];   // per queue region (A, C, B): wall_clock64 ticks and tiles
 };
 
 // LDS image of the scene for the persistent traversal kernel: [nodes | verts (float4) | tris (4 x u16)] copied verbatim

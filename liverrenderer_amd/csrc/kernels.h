@@ -622,6 +622,7 @@ k_iterate_lds(DScene sc, DRenderParams rp, DLdsInfo li, DPathStreams qin, DPathS
         __syncthreads();
         const uint32_t tile = s_tile;
         if (tile >= n_tiles) break;
+        const unsigned long long t_begin = rp.profile ? wall_clock64() : 0ull;
         bool had_path; const uint32_t i = queue_index(tile, tid, LRT_LDS_BLOCK, n_a, n_c, n_b, cap, &had_path);
         bool alive = false;
         PathState s; s.flags = 0; s.lane = 0; s.res = V3(0.f);
@@ -633,6 +634,11 @@ k_iterate_lds(DScene sc, DRenderParams rp, DLdsInfo li, DPathStreams qin, DPathS
             s.rng_state = rng.state;
         }
         retire_and_compact<LRT_LDS_BLOCK>(sc, rp, had_path, alive, s, film, sample_out, sample_base, qout, cap, cnt, s_wc, s_base);
+        if (rp.profile && tid == 0) {
+            const uint32_t ta = (n_a + LRT_LDS_BLOCK - 1) / LRT_LDS_BLOCK, tc = (n_c + LRT_LDS_BLOCK - 1) / LRT_LDS_BLOCK;
+            const int region = tile < ta ? 0 : (tile < ta + tc ? 1 : 2);
+            atomicAdd(&cnt->prof_cycles[region], wall_clock64() - t_begin); atomicAdd(&cnt->prof_tiles[region], 1ull);
+        }
     }
     for (int off = 32; off > 0; off >>= 1) { n_shadow += __shfl_down(n_shadow, off); n_extra += __shfl_down(n_extra, off); }
     if (lane_in_wave == 0 && n_shadow) atomicAdd(&cnt->n_shadow, (unsigned long long) n_shadow);
