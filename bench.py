@@ -109,7 +109,7 @@ def main():
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                "kernel": "lrt::k_iterate_lds<%d, 1024> (lrt::k_iterate<%d> when the BVH does not fit LDS)" % ((0, 0) if a.integrator == "path" else (1, 1)),
+                "kernel": "lrt::k_render<%d, 1024, true>" % (0 if a.integrator == "path" else 1),
                 "launches_per_step": launches / a.steps, "avg_launch_ms": kern_ms / max(launches, 1),
                 "alg_bytes_per_launch": alg_bytes / max(launches, 1), "iterations_per_sample": iters / (n_rank * a.steps),
                 "records_per_sample": records / (n_rank * a.steps)}

@@ -197,10 +197,10 @@ DeviceScene *device_scene_create(const lrt_scene_desc &d, int device) {
             D->lds.slot_prim = D->track(dev_upload(slot_prim.data(), slot_prim.size(), st));
             D->lds.blob_bytes = (uint32_t) blob.size(); D->lds.nodes_off = 0; D->lds.verts_off = (uint32_t) nodes_b; D->lds.tris_off = (uint32_t) (nodes_b + verts_b);
             D->lds.stack_off = (uint32_t) blob.size(); D->lds.total_bytes = (uint32_t) total;
-            HIP_CHECK(hipFuncSetAttribute((const void *) k_iterate_lds<LRT_INTEGRATOR_PATH, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) total));
-            HIP_CHECK(hipFuncSetAttribute((const void *) k_iterate_lds<LRT_INTEGRATOR_VOLPATH, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) total));
-            HIP_CHECK(hipFuncSetAttribute((const void *) k_iterate_lds<LRT_INTEGRATOR_PATH, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) total));
-            HIP_CHECK(hipFuncSetAttribute((const void *) k_iterate_lds<LRT_INTEGRATOR_VOLPATH, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) total));
+            HIP_CHECK(hipFuncSetAttribute((const void *) k_render<LRT_INTEGRATOR_PATH, 1024, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) total));
+            HIP_CHECK(hipFuncSetAttribute((const void *) k_render<LRT_INTEGRATOR_VOLPATH, 1024, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) total));
+            HIP_CHECK(hipFuncSetAttribute((const void *) k_render<LRT_INTEGRATOR_PATH, 512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) total));
+            HIP_CHECK(hipFuncSetAttribute((const void *) k_render<LRT_INTEGRATOR_VOLPATH, 512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) total));
             D->use_lds = true;
         }
     }
@@ -408,7 +408,7 @@ static DRenderParams make_params(const lrt_scene_desc &d, const ResolvedOpts &O,
     return rp;
 }
 
-struct LaunchLog { std::vector<std::pair<hipEvent_t, hipEvent_t>> launches; std::vector<uint32_t> sizes; std::vector<std::array<uint32_t, 3>> regions; size_t ev = 0; uint64_t n_iter = 0; };
+struct LaunchLog { std::vector<std::pair<hipEvent_t, hipEvent_t>> launches; std::vector<uint32_t> sizes; std::vector<std::array<uint32_t, 3>> regions; unsigned long long n_records = 0; size_t ev = 0; uint64_t n_iter = 0; };
 
 // Drains one chunk of `n` freshly generated paths sitting in q[0]: launches `iterate(cur, n)` until the queue is empty.
 template <typename Iterate>
@@ -446,7 +446,7 @@ static void finish_stats(DeviceScene *D, LaunchLog &log, hipEvent_t e_begin, hip
     HIP_CHECK(hipStreamSynchronize(st));
     HIP_CHECK(hipGetLastError());
     stats.n_samples = n_lanes; stats.n_iter = log.n_iter; stats.n_shadow = D->h_counters->n_shadow; stats.n_launches = log.launches.size();
-    stats.n_records = 0; for (uint32_t n : log.sizes) stats.n_records += n;
+    stats.n_records = log.n_records; if (!log.n_records) for (uint32_t n : log.sizes) stats.n_records += n;
     float ms = 0.f; double ksum = 0.0;
     for (size_t i = 0; i < log.launches.size(); ++i) {
         HIP_CHECK(hipEventElapsedTime(&ms, log.launches[i].first, log.launches[i].second)); ksum += ms;
@@ -457,10 +457,8 @@ static void finish_stats(DeviceScene *D, LaunchLog &log, hipEvent_t e_begin, hip
         }
     }
     stats.kernel_ms = ksum;
-    if (getenv("LRT_DEBUG_LAUNCH")) for (int r = 0; r < 3; ++r) {
-        unsigned long long host_tiles = 0; for (auto &g : log.regions) host_tiles += (g[r] + 1023) / 1024;
-        fprintf(stderr, "[lrt] region %d: host count %llu tiles\n", r, host_tiles);
-        fprintf(stderr, "[lrt] region %d: %llu tiles, %.1f ticks/tile (100 MHz wall clock)\n", r, D->h_counters->prof_tiles[r], D->h_counters->prof_tiles[r] ? (double) D->h_counters->prof_cycles[r] / D->h_counters->prof_tiles[r] : 0.0);
+    if (getenv("LRT_DEBUG_LAUNCH")) for (int r = 0; r < 4; ++r) {
+        fprintf(stderr, "[lrt] tile kind %d (0 proven-free, 1 query, 2 surface, 3 fresh): %llu tiles, %.1f ticks/tile (100 MHz wall clock)\n", r, D->h_counters->prof_tiles[r], D->h_counters->prof_tiles[r] ? (double) D->h_counters->prof_cycles[r] / D->h_counters->prof_tiles[r] : 0.0);
     }
     HIP_CHECK(hipEventElapsedTime(&ms, e_begin, e_end)); stats.total_ms = ms;
 }
@@ -471,8 +469,13 @@ static void run_wavefront(DeviceScene *D, const lrt_scene_desc &d, const Resolve
     hipStream_t st = D->stream;
     DRenderParams rp = make_params(d, O, n_lanes);
     const uint32_t chunk = (uint32_t) std::min<uint64_t>(n_lanes, 1u << 23);
-    ensure_workspace(D, 2 * std::max<uint32_t>(chunk, 1));
     const bool prb = O.integrator == LRT_INTEGRATOR_PRBVOLPATH;
+    // render kernel geometry: one 1024-thread workgroup per CU when the BVH lives in LDS, else four 256-thread ones;
+    // P = paths in flight per workgroup (multiple of 64), queues of 2P records per workgroup
+    const uint32_t n_wg = D->use_lds ? (uint32_t) D->n_cus : 4u * (uint32_t) D->n_cus;
+    const uint32_t pool_max = getenv("LRT_POOL") ? std::max(64, atoi(getenv("LRT_POOL"))) : (D->use_lds ? 32768u : 8192u);
+    const uint32_t P = (uint32_t) std::min<uint64_t>(pool_max, ((n_lanes + n_wg - 1) / n_wg + 63) / 64 * 64 + (n_lanes ? 0 : 64));
+    ensure_workspace(D, prb ? std::max<uint32_t>(chunk, 1) : (uint32_t) std::min<uint64_t>((uint64_t) n_wg * 2u * P, 0xffffffffull));
     if (prb) ensure_prb_workspace(D, std::max<uint32_t>(chunk, 1));
     HIP_CHECK(hipMemsetAsync(D->counters, 0, sizeof(DCounters), st));
     LaunchLog log;
@@ -493,42 +496,26 @@ static void run_wavefront(DeviceScene *D, const lrt_scene_desc &d, const Resolve
         finish_stats(D, log, e_begin, e_end, n_lanes, stats);
         return;
     }
-    // Streaming regeneration: every launch first tops the in-queue up with fresh camera rays (back region), so launches stay
-    // full until the lanes run out; the two-region queue keeps in-medium and surface paths in separate tiles.
-    const uint32_t cap = D->capacity;                      // = 2 * chunk: see queue_index() in kernels.h
-    uint64_t next = 0; uint32_t n_a = 0, n_c = 0, n_b = 0; int cur = 0;
-    while (next < n_lanes || n_a + n_c + n_b > 0) {
-        const uint32_t fresh = (uint32_t) std::min<uint64_t>(n_lanes - next, chunk - (n_a + n_c + n_b));
-        if (fresh) {
-            k_raygen<<<(fresh + LRT_BLOCK - 1) / LRT_BLOCK, LRT_BLOCK, 0, st>>>(D->sc, rp, D->q[cur], pixel_list, lane_begin + next, fresh, n_b, cap);
-            next += fresh; n_b += fresh;
-        }
-        HIP_CHECK(hipMemsetAsync(D->counters, 0, 4 * sizeof(uint32_t), st));      // the three region counters and the tile ticket
-        hipEvent_t a = get_event(D, log.ev++), b = get_event(D, log.ev++);
-        HIP_CHECK(hipEventRecord(a, st));
-        const bool isp = O.integrator == LRT_INTEGRATOR_PATH;
-        const uint32_t n_all = n_a + n_c + n_b;
-        if (D->use_lds) {
-            const uint32_t B = (uint32_t) D->lds_block;
-            const uint32_t g = std::min<uint32_t>((uint32_t) D->n_cus, (n_a + B - 1) / B + (n_c + B - 1) / B + (n_b + B - 1) / B);
-            #define LRT_LAUNCH_LDS(I, BS) k_iterate_lds<I, BS><<<g, BS, D->lds.total_bytes, st>>>(D->sc, rp, D->lds, D->q[cur], D->q[cur ^ 1], D->counters, n_a, n_c, n_b, cap, film, sample_out, lane_begin)
-            if (B == 512) { if (isp) LRT_LAUNCH_LDS(LRT_INTEGRATOR_PATH, 512); else LRT_LAUNCH_LDS(LRT_INTEGRATOR_VOLPATH, 512); }
-            else { if (isp) LRT_LAUNCH_LDS(LRT_INTEGRATOR_PATH, 1024); else LRT_LAUNCH_LDS(LRT_INTEGRATOR_VOLPATH, 1024); }
-            #undef LRT_LAUNCH_LDS
-        } else {
-            const uint32_t grid = (n_a + LRT_BLOCK - 1) / LRT_BLOCK + (n_c + LRT_BLOCK - 1) / LRT_BLOCK + (n_b + LRT_BLOCK - 1) / LRT_BLOCK;
-            if (isp) k_iterate<LRT_INTEGRATOR_PATH><<<grid, LRT_BLOCK, 0, st>>>(D->sc, rp, D->q[cur], D->q[cur ^ 1], D->counters, n_a, n_c, n_b, cap, film, sample_out, lane_begin);
-            else k_iterate<LRT_INTEGRATOR_VOLPATH><<<grid, LRT_BLOCK, 0, st>>>(D->sc, rp, D->q[cur], D->q[cur ^ 1], D->counters, n_a, n_c, n_b, cap, film, sample_out, lane_begin);
-        }
-        HIP_CHECK(hipEventRecord(b, st));
-        log.launches.emplace_back(a, b); log.sizes.push_back(n_all); log.regions.push_back({ n_a, n_c, n_b });
-        HIP_CHECK(hipMemcpyAsync(D->h_counters, D->counters, sizeof(DCounters), hipMemcpyDeviceToHost, st));
-        HIP_CHECK(hipStreamSynchronize(st));
-        if (count_iter) log.n_iter += n_all;
-        n_a = D->h_counters->n_out; n_c = D->h_counters->n_out_t; n_b = D->h_counters->n_out_s;
-        cur ^= 1;
+    // One persistent launch (k_render): per-workgroup path pools, in-kernel regeneration; see kernels.h.
+    const bool isp = O.integrator == LRT_INTEGRATOR_PATH;
+    hipEvent_t a = get_event(D, log.ev++), b = get_event(D, log.ev++);
+    HIP_CHECK(hipEventRecord(a, st));
+    #define LRT_LAUNCH(I, BS, LDSB, SMEM) k_render<I, BS, LDSB><<<n_wg, BS, SMEM, st>>>(D->sc, rp, D->lds, D->q[0], D->q[1], P, D->counters, pixel_list, lane_begin, film, sample_out, lane_begin)
+    if (D->use_lds) {
+        if (D->lds_block == 512) { if (isp) LRT_LAUNCH(LRT_INTEGRATOR_PATH, 512, true, D->lds.total_bytes); else LRT_LAUNCH(LRT_INTEGRATOR_VOLPATH, 512, true, D->lds.total_bytes); }
+        else { if (isp) LRT_LAUNCH(LRT_INTEGRATOR_PATH, 1024, true, D->lds.total_bytes); else LRT_LAUNCH(LRT_INTEGRATOR_VOLPATH, 1024, true, D->lds.total_bytes); }
+    } else {
+        if (isp) LRT_LAUNCH(LRT_INTEGRATOR_PATH, LRT_BLOCK, false, LRT_STACK * LRT_BLOCK * sizeof(int)); else LRT_LAUNCH(LRT_INTEGRATOR_VOLPATH, LRT_BLOCK, false, LRT_STACK * LRT_BLOCK * sizeof(int));
     }
-    if (!log.launches.empty()) log.n_iter += D->h_counters->n_iter;   // trips retired early by the look-ahead (volpath_iteration)
+    #undef LRT_LAUNCH
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipEventRecord(b, st));
+    log.launches.emplace_back(a, b); log.sizes.push_back(0);
+    HIP_CHECK(hipMemcpyAsync(D->h_counters, D->counters, sizeof(DCounters), hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    log.n_iter = count_iter ? D->h_counters->n_iter : 0;
+    log.sizes[0] = (uint32_t) std::min<unsigned long long>(D->h_counters->n_records, 0xffffffffull);
+    log.n_records = D->h_counters->n_records;
     finish_stats(D, log, e_begin, e_end, n_lanes, stats);
 }
 

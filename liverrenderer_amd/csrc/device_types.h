@@ -130,11 +130,13 @@ struct DPathStreams {
 #define PF_NOHIT        (1u << 28)     // look-ahead proved that the next free-flight segment reaches no surface
 
 struct DCounters {             // device-resident queue / statistics words
-    uint32_t n_out_t, n_out;   // survivors inside a medium: n_out = next segment proven free of surfaces (region A), n_out_t = needs a ray query (region C)
-    uint32_t tile, n_out_s;    // tile: work ticket of the persistent kernel; n_out_s: survivors outside media (region B)
-    unsigned long long n_shadow;
-    unsigned long long n_iter;
-    unsigned long long prof_cycles[3], prof_tiles[3];   // per queue region (A, C, B): wall_clock64 ticks and tiles
+    uint32_t n_in, n_out;      // PRB wavefront (kernels_prb.h): survivors of the current launch
+    uint32_t tile, pad;
+    unsigned long long n_shadow;   // NEE ray queries actually needed
+    unsigned long long n_iter;     // loop trips (render kernel)
+    unsigned long long next_lane;  // global camera-lane ticket (render kernel)
+    unsigned long long n_records;  // path records loaded from the queues
+    unsigned long long prof_cycles[4], prof_tiles[4];   // per tile kind (A, C, B, fresh): wall_clock64 ticks and tiles (LRT_DEBUG_LAUNCH)
 };
 
 // LDS image of the scene for the persistent traversal kernel: [nodes | verts (float4) | tris (4 x u16)] copied verbatim

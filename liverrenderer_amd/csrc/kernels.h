@@ -71,12 +71,9 @@ DEV Ray camera_ray(const DScene &sc, float ax, float ay) {
     return ray;
 }
 
-__global__ void __launch_bounds__(LRT_BLOCK)
-k_raygen(DScene sc, DRenderParams rp, DPathStreams q, const uint32_t *__restrict__ pixel_list,
-         uint64_t lane_base, uint32_t n, uint32_t back_base, uint32_t cap) {
-    uint32_t i = blockIdx.x * LRT_BLOCK + threadIdx.x;
-    if (i >= n) return;
-    uint64_t j = lane_base + i;                       // rank-local lane
+// A fresh camera path for rank-local lane index j (integrator.cpp:321-338,449-470; volpath.cpp:93-140 /
+// path.cpp:95-170 up to the loop).
+DEV PathState generate_camera_path(const DScene &sc, const DRenderParams &rp, const uint32_t *__restrict__ pixel_list, uint64_t j) {
     uint32_t lane;
     if (pixel_list) { uint32_t pj = (uint32_t) (j / rp.spp); lane = pixel_list[pj] * rp.spp + (uint32_t) (j - (uint64_t) pj * rp.spp); }
     else lane = (uint32_t) j;
@@ -97,7 +94,7 @@ k_raygen(DScene sc, DRenderParams rp, DPathStreams q, const uint32_t *__restrict
         flags |= (uint32_t) (sc.cam.medium + 1) << PF_MEDIUM_SHIFT;
     }
     s.flags = flags; s.rng_state = rng.state;
-    store_state(q, cap - 1u - (back_base + i), s);          // camera rays start outside media: back region of the queue
+    return s;
 }
 
 // ------------------------------------------------------------------ film
@@ -526,123 +523,130 @@ DEV bool path_iteration(const DScene &sc, const DRenderParams &rp, PathState &s,
     return active;
 }
 
-// ---- queues.  A queue (one set of path streams of `cap` records, cap = 2 x the paths in flight) holds three regions:
-//   A  [0, n_a)                 in-medium paths whose next segment is proven free of surfaces (no ray query)
-//   C  [cap/2, cap/2 + n_c)     in-medium paths that need their ray query
-//   B  cap-1-j, j in [0, n_b)   paths outside media (camera rays, surface bounces)
-// n_a + n_b + n_c <= cap/2, so the regions never collide.  Tiles never mix populations, which keeps a wave's lanes on
-// the same branch of the loop body.
-DEV uint32_t queue_index(uint32_t tile, uint32_t tid, uint32_t B, uint32_t n_a, uint32_t n_c, uint32_t n_b, uint32_t cap, bool *valid) {
-    const uint32_t tiles_a = (n_a + B - 1) / B, tiles_c = (n_c + B - 1) / B;
-    if (tile < tiles_a) { uint32_t i = tile * B + tid; *valid = i < n_a; return i; }
-    if (tile < tiles_a + tiles_c) { uint32_t i = (tile - tiles_a) * B + tid; *valid = i < n_c; return (cap >> 1) + i; }
-    uint32_t j = (tile - tiles_a - tiles_c) * B + tid; *valid = j < n_b; return cap - 1u - j;
+// ---- the render kernel.  ONE launch per lrt_render: every workgroup is persistent and owns a private pool of path records
+// in HBM (two queues of cap = 2P records, P = paths in flight per workgroup).  A round of a workgroup:
+//   1. top the pool up to P paths with fresh camera lanes, taken from the global lane ticket (one atomic per round);
+//   2. its waves pull 64-path tiles from an LDS ticket, independently of each other (no workgroup barrier inside a
+//      round, so one wave's memory latency is hidden by the other waves of its SIMD); a tile is one region of the in-queue
+//      or a batch of fresh lanes, which are generated in registers and run their first trip without touching HBM;
+//   3. survivors go to the out-queue (slots from LDS counters: wave ballot + one LDS atomic per region), finished paths
+//      are reduced per pixel inside the wave and splatted;  barrier, swap queues.
+// A queue holds three regions, so that a wave's lanes stay on the same branch of the loop body:
+//   A  [0, n_a)            in-medium paths whose next segment is proven free of surfaces (no ray query)
+//   C  [P, P + n_c)        in-medium paths that need their ray query
+//   B  2P-1-j, j < n_b     paths outside media
+// n_a + n_b + n_c <= P, so the regions never collide.  No cross-workgroup dependency exists besides the lane ticket and the
+// film atomics; every wave leaves its loops once the ticket is exhausted and its pool is empty.
+DEV DPathStreams offset_streams(const DPathStreams &q, size_t off) {
+    DPathStreams r; r.o_maxt = q.o_maxt + off; r.d_eta = q.d_eta + off; r.tp_pdf = q.tp_pdf + off; r.res_flags = q.res_flags + off; r.lp_lane = q.lp_lane + off; r.rng = q.rng + off;
+    return r;
 }
-DEV uint32_t queue_tiles(uint32_t B, uint32_t n_a, uint32_t n_c, uint32_t n_b) { return (n_a + B - 1) / B + (n_c + B - 1) / B + (n_b + B - 1) / B; }
 
-// Retires finished paths into the film and appends survivors to the out queue: __ballot + popcount prefix inside the
-// wave, one atomic per region and workgroup.  Called by every thread of the workgroup (two barriers inside).
-template <int B>
-DEV void retire_and_compact(const DScene &sc, const DRenderParams &rp, bool had_path, bool alive, const PathState &s,
-                            float *__restrict__ film, float *__restrict__ sample_out, uint64_t sample_base,
-                            const DPathStreams &qout, uint32_t cap, DCounters *__restrict__ cnt,
-                            uint32_t (*s_wc)[B / 64] /* [3] */, uint32_t *s_base /* [3] */) {
-    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane_in_wave = tid & 63u;
+DEV void retire_and_compact_wave(const DScene &sc, const DRenderParams &rp, bool had_path, bool alive, const PathState &s,
+                                 float *__restrict__ film, float *__restrict__ sample_out, uint64_t sample_base,
+                                 const DPathStreams &qout, uint32_t P, uint32_t *s_out /* LDS [3] */) {
+    const uint32_t lane_in_wave = threadIdx.x & 63u;
     finish_paths_wave(sc, rp, film, sample_out, sample_base, had_path && !alive, s.lane, s.res, (s.flags & PF_VALID) != 0);
     const int region = !(s.flags & PF_MEDIUM_MASK) ? 2 : ((s.flags & PF_NOHIT) ? 0 : 1);
     const unsigned long long m0 = __ballot(alive && region == 0), m1 = __ballot(alive && region == 1), m2 = __ballot(alive && region == 2);
-    const unsigned long long below = (1ull << lane_in_wave) - 1ull;
-    if (lane_in_wave == 0) { s_wc[0][wave] = (uint32_t) __popcll(m0); s_wc[1][wave] = (uint32_t) __popcll(m1); s_wc[2][wave] = (uint32_t) __popcll(m2); }
-    __syncthreads();
-    if (tid < 3) {
-        uint32_t t = 0;
-        for (int w = 0; w < B / 64; ++w) t += s_wc[tid][w];
-        uint32_t *dst = tid == 0 ? &cnt->n_out : (tid == 1 ? &cnt->n_out_t : &cnt->n_out_s);
-        s_base[tid] = t ? atomicAdd(dst, t) : 0u;
+    uint32_t base = 0;
+    if (lane_in_wave < 3) {
+        const uint32_t c = (uint32_t) __popcll(lane_in_wave == 0 ? m0 : (lane_in_wave == 1 ? m1 : m2));
+        if (c) base = atomicAdd(&s_out[lane_in_wave], c);
     }
-    __syncthreads();
+    const uint32_t b = __shfl(base, region);
     if (alive) {
         const unsigned long long mine = region == 0 ? m0 : (region == 1 ? m1 : m2);
-        uint32_t slot = s_base[region] + (uint32_t) __popcll(mine & below);
-        for (uint32_t w = 0; w < wave; ++w) slot += s_wc[region][w];
-        store_state(qout, region == 0 ? slot : (region == 1 ? (cap >> 1) + slot : cap - 1u - slot), s);
+        const uint32_t slot = b + (uint32_t) __popcll(mine & ((1ull << lane_in_wave) - 1ull));
+        store_state(qout, region == 0 ? slot : (region == 1 ? P + slot : 2u * P - 1u - slot), s);
     }
 }
 
-// Grid-launched variant: BVH in global memory (any scene size), one 256-path tile per workgroup.
-template <int INTEGRATOR>
-__global__ void __launch_bounds__(LRT_BLOCK)
-k_iterate(DScene sc, DRenderParams rp, DPathStreams qin, DPathStreams qout, DCounters *__restrict__ cnt, uint32_t n_a, uint32_t n_c, uint32_t n_b, uint32_t cap,
-          float *__restrict__ film, float *__restrict__ sample_out, uint64_t sample_base) {
-    __shared__ int s_stack[LRT_STACK * LRT_BLOCK];
-    __shared__ uint32_t s_wc[3][LRT_BLOCK / 64], s_base[3];
-    const uint32_t tid = threadIdx.x;
-    bool had_path; const uint32_t i = queue_index(blockIdx.x, tid, LRT_BLOCK, n_a, n_c, n_b, cap, &had_path);
-    bool alive = false;
-    PathState s; s.flags = 0; s.lane = 0; s.res = V3(0.f);
-    uint32_t n_shadow = 0, n_extra = 0;
-    if (had_path) {
-        load_state(qin, i, s);
-        PCG32 rng; rng.state = s.rng_state; rng.inc = lane_rng_inc(rp.seed_value, s.lane);
-        const GlobalTracer tr{ sc, s_stack + tid };
-        if (INTEGRATOR == LRT_INTEGRATOR_PATH) alive = path_iteration(sc, rp, s, rng, tr, n_shadow);
-        else alive = volpath_iteration(sc, rp, s, rng, tr, n_shadow, n_extra);
-        s.rng_state = rng.state;
-    }
-    retire_and_compact<LRT_BLOCK>(sc, rp, had_path, alive, s, film, sample_out, sample_base, qout, cap, cnt, s_wc, s_base);
-    for (int off = 32; off > 0; off >>= 1) { n_shadow += __shfl_down(n_shadow, off); n_extra += __shfl_down(n_extra, off); }
-    if ((tid & 63u) == 0 && n_shadow) atomicAdd(&cnt->n_shadow, (unsigned long long) n_shadow);
-    if ((tid & 63u) == 0 && n_extra) atomicAdd(&cnt->n_iter, (unsigned long long) n_extra);
-}
-
-// Persistent variant for scenes whose BVH fits in LDS: one 1024-thread workgroup per CU copies the scene image into
-// LDS once, then pulls tiles from a ticket counter until both regions of the in-queue are drained.
-template <int INTEGRATOR, int LRT_LDS_BLOCK>
-__global__ void __launch_bounds__(LRT_LDS_BLOCK)
-k_iterate_lds(DScene sc, DRenderParams rp, DLdsInfo li, DPathStreams qin, DPathStreams qout, DCounters *__restrict__ cnt,
-              uint32_t n_a, uint32_t n_c, uint32_t n_b, uint32_t cap, float *__restrict__ film, float *__restrict__ sample_out, uint64_t sample_base) {
+template <int INTEGRATOR, int BLOCK, bool LDS_BVH>
+__global__ void __launch_bounds__(BLOCK)
+k_render(DScene sc, DRenderParams rp, DLdsInfo li, DPathStreams q0, DPathStreams q1, uint32_t P, DCounters *__restrict__ cnt,
+         const uint32_t *__restrict__ pixel_list, uint64_t lane_begin, float *__restrict__ film, float *__restrict__ sample_out, uint64_t sample_base) {
     extern __shared__ __align__(16) unsigned char smem[];
-    __shared__ uint32_t s_wc[3][LRT_LDS_BLOCK / 64], s_base[3];
-    __shared__ uint32_t s_tile;
+    __shared__ uint32_t s_in[3], s_out[3], s_ticket, s_fresh;
+    __shared__ unsigned long long s_fresh_base;
     const uint32_t tid = threadIdx.x, lane_in_wave = tid & 63u;
-    {
+    LdsScene L{};
+    if (LDS_BVH) {
         const uint4 *src = li.blob; uint4 *dst = reinterpret_cast<uint4 *>(smem);
-        for (uint32_t k = tid; k < li.blob_bytes / 16u; k += LRT_LDS_BLOCK) dst[k] = src[k];
+        for (uint32_t k = tid; k < li.blob_bytes / 16u; k += BLOCK) dst[k] = src[k];
+        L.nodes = reinterpret_cast<const float4 *>(smem + li.nodes_off); L.verts = reinterpret_cast<const float4 *>(smem + li.verts_off);
+        L.tris = reinterpret_cast<const uint2 *>(smem + li.tris_off); L.slot_prim = li.slot_prim;
+        L.n_faces = sc.n_faces; L.root_is_leaf = (uint32_t) sc.root_is_leaf; L.root_first = sc.root_leaf_first; L.root_count = sc.root_leaf_count;
     }
-    LdsScene L;
-    L.nodes = reinterpret_cast<const float4 *>(smem + li.nodes_off); L.verts = reinterpret_cast<const float4 *>(smem + li.verts_off);
-    L.tris = reinterpret_cast<const uint2 *>(smem + li.tris_off); L.slot_prim = li.slot_prim;
-    L.n_faces = sc.n_faces; L.root_is_leaf = (uint32_t) sc.root_is_leaf; L.root_first = sc.root_leaf_first; L.root_count = sc.root_leaf_count;
-    const LdsTracer<LRT_LDS_BLOCK> tr{ L, reinterpret_cast<uint16_t *>(smem + li.stack_off) + tid };
-    const uint32_t n_tiles = queue_tiles(LRT_LDS_BLOCK, n_a, n_c, n_b);
-    uint32_t n_shadow = 0, n_extra = 0;
-    __syncthreads();
+    const LdsTracer<BLOCK> tr_lds{ L, reinterpret_cast<uint16_t *>(smem + li.stack_off) + tid };
+    const GlobalTracer tr_glb{ sc, reinterpret_cast<int *>(smem) + tid };
+    const size_t pool = (size_t) blockIdx.x * 2u * P;
+    DPathStreams qin = offset_streams(q0, pool), qout = offset_streams(q1, pool);
+    if (tid == 0) { s_in[0] = s_in[1] = s_in[2] = 0; }
+    bool lanes_left = true;                                   // thread 0
+    uint32_t n_shadow = 0, n_extra = 0, n_trips = 0, n_loaded = 0;
     for (;;) {
-        if (tid == 0) s_tile = atomicAdd(&cnt->tile, 1u);
+        if (tid == 0) {
+            const uint32_t want = P - (s_in[0] + s_in[1] + s_in[2]);
+            uint32_t got = 0; unsigned long long base = 0;
+            if (want && lanes_left) {
+                base = atomicAdd(&cnt->next_lane, (unsigned long long) want);
+                if (base < rp.n_lanes) got = (uint32_t) (rp.n_lanes - base < (unsigned long long) want ? rp.n_lanes - base : (unsigned long long) want);
+                lanes_left = base + want < rp.n_lanes;
+            }
+            s_fresh = got; s_fresh_base = base; s_ticket = 0; s_out[0] = s_out[1] = s_out[2] = 0;
+        }
         __syncthreads();
-        const uint32_t tile = s_tile;
-        if (tile >= n_tiles) break;
-        const unsigned long long t_begin = rp.profile ? wall_clock64() : 0ull;
-        bool had_path; const uint32_t i = queue_index(tile, tid, LRT_LDS_BLOCK, n_a, n_c, n_b, cap, &had_path);
-        bool alive = false;
-        PathState s; s.flags = 0; s.lane = 0; s.res = V3(0.f);
-        if (had_path) {
-            load_state(qin, i, s);
-            PCG32 rng; rng.state = s.rng_state; rng.inc = lane_rng_inc(rp.seed_value, s.lane);
-            if (INTEGRATOR == LRT_INTEGRATOR_PATH) alive = path_iteration(sc, rp, s, rng, tr, n_shadow);
-            else alive = volpath_iteration(sc, rp, s, rng, tr, n_shadow, n_extra);
-            s.rng_state = rng.state;
+        const uint32_t n_a = s_in[0], n_c = s_in[1], n_b = s_in[2], fresh = s_fresh;
+        const unsigned long long fresh_base = s_fresh_base;
+        if (n_a + n_c + n_b + fresh == 0) break;
+        const uint32_t ta = (n_a + 63u) >> 6, tc = (n_c + 63u) >> 6, tb = (n_b + 63u) >> 6, tf = (fresh + 63u) >> 6;
+        const uint32_t n_tiles = ta + tc + tb + tf;
+        for (;;) {
+            uint32_t t = 0;
+            if (lane_in_wave == 0) t = atomicAdd(&s_ticket, 1u);
+            t = (uint32_t) __builtin_amdgcn_readfirstlane((int) t);
+            if (t >= n_tiles) break;
+            const unsigned long long t_begin = rp.profile ? wall_clock64() : 0ull;
+            bool had_path = false, alive = false;
+            PathState s; s.flags = 0; s.lane = 0; s.res = V3(0.f);
+            if (t < ta + tc + tb) {
+                uint32_t i;
+                if (t < ta) { i = (t << 6) + lane_in_wave; had_path = i < n_a; }
+                else if (t < ta + tc) { i = ((t - ta) << 6) + lane_in_wave; had_path = i < n_c; i += P; }
+                else { i = ((t - ta - tc) << 6) + lane_in_wave; had_path = i < n_b; i = 2u * P - 1u - i; }
+                if (had_path) { load_state(qin, i, s); n_loaded += 1; }
+            } else {
+                const uint32_t i = ((t - ta - tc - tb) << 6) + lane_in_wave;
+                had_path = i < fresh;
+                if (had_path) s = generate_camera_path(sc, rp, pixel_list, lane_begin + fresh_base + i);
+            }
+            if (had_path) {
+                PCG32 rng; rng.state = s.rng_state; rng.inc = lane_rng_inc(rp.seed_value, s.lane);
+                if (INTEGRATOR == LRT_INTEGRATOR_PATH) alive = LDS_BVH ? path_iteration(sc, rp, s, rng, tr_lds, n_shadow) : path_iteration(sc, rp, s, rng, tr_glb, n_shadow);
+                else alive = LDS_BVH ? volpath_iteration(sc, rp, s, rng, tr_lds, n_shadow, n_extra) : volpath_iteration(sc, rp, s, rng, tr_glb, n_shadow, n_extra);
+                s.rng_state = rng.state;
+                n_trips += 1;
+            }
+            retire_and_compact_wave(sc, rp, had_path, alive, s, film, sample_out, sample_base, qout, P, s_out);
+            if (rp.profile && lane_in_wave == 0) {
+                const int region = t < ta ? 0 : (t < ta + tc ? 1 : (t < ta + tc + tb ? 2 : 3));
+                atomicAdd(&cnt->prof_cycles[region], wall_clock64() - t_begin); atomicAdd(&cnt->prof_tiles[region], 1ull);
+            }
         }
-        retire_and_compact<LRT_LDS_BLOCK>(sc, rp, had_path, alive, s, film, sample_out, sample_base, qout, cap, cnt, s_wc, s_base);
-        if (rp.profile && tid == 0) {
-            const uint32_t ta = (n_a + LRT_LDS_BLOCK - 1) / LRT_LDS_BLOCK, tc = (n_c + LRT_LDS_BLOCK - 1) / LRT_LDS_BLOCK;
-            const int region = tile < ta ? 0 : (tile < ta + tc ? 1 : 2);
-            atomicAdd(&cnt->prof_cycles[region], wall_clock64() - t_begin); atomicAdd(&cnt->prof_tiles[region], 1ull);
-        }
+        __syncthreads();
+        if (tid == 0) { s_in[0] = s_out[0]; s_in[1] = s_out[1]; s_in[2] = s_out[2]; }
+        const DPathStreams tmp = qin; qin = qout; qout = tmp;
     }
-    for (int off = 32; off > 0; off >>= 1) { n_shadow += __shfl_down(n_shadow, off); n_extra += __shfl_down(n_extra, off); }
-    if (lane_in_wave == 0 && n_shadow) atomicAdd(&cnt->n_shadow, (unsigned long long) n_shadow);
-    if (lane_in_wave == 0 && n_extra) atomicAdd(&cnt->n_iter, (unsigned long long) n_extra);
+    n_trips += n_extra;
+    for (int off = 32; off > 0; off >>= 1) {
+        n_shadow += __shfl_down(n_shadow, off); n_trips += __shfl_down(n_trips, off); n_loaded += __shfl_down(n_loaded, off);
+    }
+    if (lane_in_wave == 0) {
+        if (n_shadow) atomicAdd(&cnt->n_shadow, (unsigned long long) n_shadow);
+        if (n_trips) atomicAdd(&cnt->n_iter, (unsigned long long) n_trips);
+        if (n_loaded) atomicAdd(&cnt->n_records, (unsigned long long) n_loaded);
+    }
 }
 
 // Distance field build (scene upload): one thread per cell, exact point-triangle distance (closest-feature regions of
