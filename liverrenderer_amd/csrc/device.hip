@@ -182,7 +182,7 @@ DeviceScene *device_scene_create(const lrt_scene_desc &d, int device) {
         D->lds_block = getenv("LRT_LDS_BLOCK") ? atoi(getenv("LRT_LDS_BLOCK")) : 1024; if (D->lds_block != 512) D->lds_block = 1024;
         const size_t stack_b = (size_t) 2 * LRT_LDS_STACK * D->lds_block, total = nodes_b + verts_b + tris_b + stack_b;
         const size_t lds_limit = std::min<size_t>((size_t) prop.sharedMemPerBlock ? 160 * 1024 : 64 * 1024, 160 * 1024) - 512;
-        if (d.n_faces > 0 && n_verts <= 65535 && n_nodes <= 32767 && bvh.max_depth < LRT_LDS_STACK && total <= lds_limit && !getenv("LRT_NO_LDS_BVH")) {
+        if (d.n_faces > 0 && n_verts <= 65535 && n_nodes <= 32767 && n_slots <= 32767 && bvh.max_depth < LRT_LDS_STACK && total <= lds_limit && !getenv("LRT_NO_LDS_BVH")) {
             std::vector<unsigned char> blob(nodes_b + verts_b + tris_b, 0);
             memcpy(blob.data(), bvh.nodes.data(), nodes_b);
             float *v = reinterpret_cast<float *>(blob.data() + nodes_b);
@@ -192,6 +192,10 @@ DeviceScene *device_scene_create(const lrt_scene_desc &d, int device) {
             for (size_t sl = 0; sl < n_slots; ++sl) {
                 uint32_t f; memcpy(&f, &bvh.tris[12 * sl + 3], 4); slot_prim[sl] = f;
                 for (int k = 0; k < 3; ++k) t[4 * sl + k] = (uint16_t) d.faces[3 * (size_t) f + k];
+            }
+            for (size_t n = 0; n < n_nodes; ++n) {                 // mark the last slot of every leaf (trace_lds)
+                int32_t refs[4]; memcpy(refs, &bvh.nodes[16 * n + 12], 16);
+                for (int c = 0; c < 2; ++c) if (refs[c] < 0 && refs[2 + c] > 0) t[4 * ((size_t) (uint32_t) ~refs[c] + (size_t) refs[2 + c] - 1) + 3] = 1;
             }
             D->lds.blob = (const uint4 *) D->track(dev_upload(blob.data(), blob.size(), st));
             D->lds.slot_prim = D->track(dev_upload(slot_prim.data(), slot_prim.size(), st));
@@ -403,7 +407,7 @@ static DRenderParams make_params(const lrt_scene_desc &d, const ResolvedOpts &O,
     DRenderParams rp{};
     rp.integrator = O.integrator; rp.max_depth = O.max_depth; rp.rr_depth = O.rr_depth; rp.hide_emitters = O.hide_emitters;
     rp.spp = O.spp; rp.log2_spp = ((O.spp & (O.spp - 1)) == 0) ? (uint32_t) __builtin_ctz(O.spp) : 0xffffffffu;
-    rp.profile = getenv("LRT_DEBUG_LAUNCH") ? 1u : 0u;
+    rp.profile = (getenv("LRT_DEBUG_LAUNCH") ? 1u : 0u) | (getenv("LRT_EXP") ? (uint32_t) atoi(getenv("LRT_EXP")) : 0u);
     rp.seed_value = d.sampler_seed + O.seed; rp.tile_rank = O.tile_rank; rp.tile_count = O.tile_count; rp.n_lanes = n_lanes;
     return rp;
 }

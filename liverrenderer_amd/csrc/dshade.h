@@ -136,41 +136,46 @@ DEV Hit trace_lds(const LdsScene &L, const Ray &r, uint16_t *__restrict__ stack 
     }
     // The slab arithmetic only culls (hits are decided by the Moeller-Trumbore tests and the tie rule), so it may differ
     // from the oracle's: approximate reciprocal, one fma per plane, 3-input min/max.  The padded boxes absorb the error.
+    // "while-while" traversal: every lane first descends to its next leaf (inner loop: box tests only), then the lanes
+    // test their leaf triangles together; this keeps far more lanes busy than testing leaves where they are met.
+    // Work items are 16-bit: inner node index (< 0x8000) or 0x8000 | first triangle slot; a leaf ends at the slot whose
+    // index word carries the "last" flag (device.hip).
     const float ix = __builtin_amdgcn_rcpf(d.x), iy = __builtin_amdgcn_rcpf(d.y), iz = __builtin_amdgcn_rcpf(d.z);
     const float ox = -o.x * ix, oy = -o.y * iy, oz = -o.z * iz;
-    int sp = 0, node = 0;
+    const uint32_t DONE = 0x10000u;
+    int sp = 0; uint32_t cur = 0;
     for (;;) {
-        const float4 *nd = L.nodes + 4 * node;
-        float4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3];
-        float limit = fmin_(best.t, r.maxt);
-        float ax0 = fma_(n0.x, ix, ox), ax1 = fma_(n0.y, ix, ox), ay0 = fma_(n0.z, iy, oy), ay1 = fma_(n0.w, iy, oy), az0 = fma_(n2.x, iz, oz), az1 = fma_(n2.y, iz, oz);
-        float bx0 = fma_(n1.x, ix, ox), bx1 = fma_(n1.y, ix, ox), by0 = fma_(n1.z, iy, oy), by1 = fma_(n1.w, iy, oy), bz0 = fma_(n2.z, iz, oz), bz1 = fma_(n2.w, iz, oz);
-        float tmin0 = fmax_(fmax_(fmin_(ax0, ax1), fmin_(ay0, ay1)), fmax_(fmin_(az0, az1), 0.f));
-        float tmax0 = fmin_(fmin_(fmax_(ax0, ax1), fmax_(ay0, ay1)), fmin_(fmax_(az0, az1), limit));
-        float tmin1 = fmax_(fmax_(fmin_(bx0, bx1), fmin_(by0, by1)), fmax_(fmin_(bz0, bz1), 0.f));
-        float tmax1 = fmin_(fmin_(fmax_(bx0, bx1), fmax_(by0, by1)), fmin_(fmax_(bz0, bz1), limit));
-        bool h0 = tmin0 <= tmax0 * 1.000002f + 1e-30f, h1 = tmin1 <= tmax1 * 1.000002f + 1e-30f;
-        int r0 = (int) f2u(n3.x), r1 = (int) f2u(n3.y);
-        int next = 0x7fffffff;
-        if (h0 && h1) {
-            bool swap = tmin1 < tmin0;
-            int nearr = swap ? r1 : r0, farr = swap ? r0 : r1;
-            int nearc = swap ? (int) f2u(n3.w) : (int) f2u(n3.z), farc = swap ? (int) f2u(n3.z) : (int) f2u(n3.w);
-            if (nearr < 0) { uint32_t first = (uint32_t) ~nearr; for (int i = 0; i < nearc; ++i) test_tri_lds(L, first + i, o, d, r.maxt, best); }
-            if (farr < 0) { uint32_t first = (uint32_t) ~farr; for (int i = 0; i < farc; ++i) test_tri_lds(L, first + i, o, d, r.maxt, best); }
-            if (nearr >= 0) { next = nearr; if (farr >= 0) { stack[sp * STRIDE] = (uint16_t) farr; ++sp; } }
-            else if (farr >= 0) next = farr;
-        } else if (h0 || h1) {
-            int rr = h0 ? r0 : r1, cc = h0 ? (int) f2u(n3.z) : (int) f2u(n3.w);
-            if (rr < 0) { uint32_t first = (uint32_t) ~rr; for (int i = 0; i < cc; ++i) test_tri_lds(L, first + i, o, d, r.maxt, best); }
-            else next = rr;
+        while (cur < 0x8000u) {
+            const float4 *nd = L.nodes + 4 * cur;
+            float4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3];
+            float limit = fmin_(best.t, r.maxt);
+            float ax0 = fma_(n0.x, ix, ox), ax1 = fma_(n0.y, ix, ox), ay0 = fma_(n0.z, iy, oy), ay1 = fma_(n0.w, iy, oy), az0 = fma_(n2.x, iz, oz), az1 = fma_(n2.y, iz, oz);
+            float bx0 = fma_(n1.x, ix, ox), bx1 = fma_(n1.y, ix, ox), by0 = fma_(n1.z, iy, oy), by1 = fma_(n1.w, iy, oy), bz0 = fma_(n2.z, iz, oz), bz1 = fma_(n2.w, iz, oz);
+            float tmin0 = fmax_(fmax_(fmin_(ax0, ax1), fmin_(ay0, ay1)), fmax_(fmin_(az0, az1), 0.f));
+            float tmax0 = fmin_(fmin_(fmax_(ax0, ax1), fmax_(ay0, ay1)), fmin_(fmax_(az0, az1), limit));
+            float tmin1 = fmax_(fmax_(fmin_(bx0, bx1), fmin_(by0, by1)), fmax_(fmin_(bz0, bz1), 0.f));
+            float tmax1 = fmin_(fmin_(fmax_(bx0, bx1), fmax_(by0, by1)), fmin_(fmax_(bz0, bz1), limit));
+            bool h0 = tmin0 <= tmax0 * 1.000002f + 1e-30f, h1 = tmin1 <= tmax1 * 1.000002f + 1e-30f;
+            int r0 = (int) f2u(n3.x), r1 = (int) f2u(n3.y);
+            uint32_t c0 = r0 < 0 ? (0x8000u | (uint32_t) ~r0) : (uint32_t) r0, c1 = r1 < 0 ? (0x8000u | (uint32_t) ~r1) : (uint32_t) r1;
+            if (h0 && h1) {
+                bool swap = tmin1 < tmin0;
+                stack[sp * STRIDE] = (uint16_t) (swap ? c0 : c1); ++sp;
+                cur = swap ? c1 : c0;
+            } else if (h0 || h1) cur = h0 ? c0 : c1;
+            else if (sp == 0) cur = DONE;
+            else { --sp; cur = stack[sp * STRIDE]; }
         }
+        if (cur == DONE) break;
+        uint32_t slot = cur & 0x7fffu, last;
+        do {
+            last = L.tris[slot].y >> 16;
+            test_tri_lds(L, slot, o, d, r.maxt, best);
+            ++slot;
+        } while (!last);
         if (ANY_HIT && best.prim != 0xffffffffu) return best;
-        if (next == 0x7fffffff) {
-            if (sp == 0) break;
-            --sp; next = stack[sp * STRIDE];
-        }
-        node = next;
+        if (sp == 0) break;
+        --sp; cur = stack[sp * STRIDE];
     }
     return best;
 }

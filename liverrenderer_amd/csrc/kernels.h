@@ -172,7 +172,17 @@ DEV void finish_paths_wave(const DScene &sc, const DRenderParams &rp, float *__r
     float a = valid ? 1.f : 0.f;
     unsigned long long todo = __ballot(finishing);
     const uint32_t me = threadIdx.x & 63u;
+    if (rp.profile & 2u) return;
+    int rounds = 0;
     while (todo) {
+        if ((rp.profile & 4u) && rounds++ >= 2) {
+            if (finishing && ((todo >> me) & 1ull)) {
+                float *p = film + (size_t) pixel * F.channels;
+                atomicAdd(p + 0, L.x); atomicAdd(p + 1, L.y); atomicAdd(p + 2, L.z);
+                if (F.has_alpha) { atomicAdd(p + 3, a); atomicAdd(p + 4, 1.f); } else atomicAdd(p + 3, 1.f);
+            }
+            break;
+        }
         int leader = __ffsll((long long) todo) - 1;
         uint32_t key = __shfl(pixel, leader);
         bool mine = finishing && pixel == key;
@@ -607,7 +617,7 @@ k_render(DScene sc, DRenderParams rp, DLdsInfo li, DPathStreams q0, DPathStreams
             if (lane_in_wave == 0) t = atomicAdd(&s_ticket, 1u);
             t = (uint32_t) __builtin_amdgcn_readfirstlane((int) t);
             if (t >= n_tiles) break;
-            const unsigned long long t_begin = rp.profile ? wall_clock64() : 0ull;
+            const unsigned long long t_begin = (rp.profile & 1u) ? wall_clock64() : 0ull;
             bool had_path = false, alive = false;
             PathState s; s.flags = 0; s.lane = 0; s.res = V3(0.f);
             if (t < ta + tc + tb) {
@@ -629,7 +639,7 @@ k_render(DScene sc, DRenderParams rp, DLdsInfo li, DPathStreams q0, DPathStreams
                 n_trips += 1;
             }
             retire_and_compact_wave(sc, rp, had_path, alive, s, film, sample_out, sample_base, qout, P, s_out);
-            if (rp.profile && lane_in_wave == 0) {
+            if ((rp.profile & 1u) && lane_in_wave == 0) {
                 const int region = t < ta ? 0 : (t < ta + tc ? 1 : (t < ta + tc + tb ? 2 : 3));
                 atomicAdd(&cnt->prof_cycles[region], wall_clock64() - t_begin); atomicAdd(&cnt->prof_tiles[region], 1ull);
             }
