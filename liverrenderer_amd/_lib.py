@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libliverrt.so")
+LIB_PATH = os.environ.get("LRT_LIBRARY") or os.path.join(_HERE, "libliverrt.so")     # LRT_LIBRARY: developer builds (csrc/Makefile: exp)
 
 OK = 0
 INTEGRATOR = {"path": 0, "volpath": 1, "prbvolpath": 2}

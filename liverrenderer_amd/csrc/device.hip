@@ -215,7 +215,7 @@ DeviceScene *device_scene_create(const lrt_scene_desc &d, int device) {
         float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
         for (uint32_t f = 0; f < 3 * d.n_faces; ++f) for (int a = 0; a < 3; ++a) { float v = d.positions[3 * (size_t) d.faces[f] + a]; lo[a] = std::min(lo[a], v); hi[a] = std::max(hi[a], v); }
         const float ext = std::max(hi[0] - lo[0], std::max(hi[1] - lo[1], hi[2] - lo[2]));
-        const int res = getenv("LRT_DIST_GRID_RES") ? std::max(8, std::min(256, atoi(getenv("LRT_DIST_GRID_RES")))) : (d.n_faces <= (1u << 14) ? 128 : 64);
+        const int res = getenv("LRT_DIST_GRID_RES") ? std::max(8, std::min(256, atoi(getenv("LRT_DIST_GRID_RES")))) : (d.n_faces <= (1u << 14) ? 192 : 64);
         if (ext > 0.f && std::isfinite(ext)) {
             DDistGrid g{};
             g.cell = ext / (float) res; g.inv_cell = 1.f / g.cell;

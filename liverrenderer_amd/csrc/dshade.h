@@ -191,24 +191,27 @@ struct LdsTracer {
 // Lower bound of the distance from p to the nearest triangle (0: unknown / outside the grid).  |p - centre| is subtracted
 // exactly (1-Lipschitz), the stored value already carries the safety margins (device.hip: build_dist_grid).
 DEV float dist_grid_lower_bound(const DDistGrid &g, V3 p) {
+    // D(c) - |p - c| bounds the distance for ANY p, so the cell index is simply clamped into the grid (a point outside the
+    // grid gets a small or negative bound; NaN coordinates give NaN, which proves nothing).
     float fx = (p.x - g.lo[0]) * g.inv_cell, fy = (p.y - g.lo[1]) * g.inv_cell, fz = (p.z - g.lo[2]) * g.inv_cell;
-    bool inside = fx >= 0.f && fy >= 0.f && fz >= 0.f && fx < (float) g.n[0] && fy < (float) g.n[1] && fz < (float) g.n[2];
-    if (!inside) return 0.f;
-    int ix = (int) fx, iy = (int) fy, iz = (int) fz;
-    float D = g.d[((size_t) iz * (size_t) g.n[1] + (size_t) iy) * (size_t) g.n[0] + (size_t) ix];
+    int ix = min(max((int) fx, 0), g.n[0] - 1), iy = min(max((int) fy, 0), g.n[1] - 1), iz = min(max((int) fz, 0), g.n[2] - 1);
+    float D = g.d[(uint32_t) ((iz * g.n[1] + iy) * g.n[0] + ix)];
     float cx = fx - ((float) ix + .5f), cy = fy - ((float) iy + .5f), cz = fz - ((float) iz + .5f);
-    return D - __builtin_sqrtf(cx * cx + cy * cy + cz * cz) * g.cell * 1.001f;
+    return D - __builtin_amdgcn_sqrtf(cx * cx + cy * cy + cz * cz) * (g.cell * 1.001f);   // 1-ulp hardware sqrt: inside the margins
 }
 
 // True when the segment o + t d, t in [0, maxt], provably meets no triangle: a few sphere-tracing steps through the
 // distance field.  Margins: 1 % on the segment length, every advance counted 0.5 % short (f32 error of the
 // Moller-Trumbore t is ~1e-6 relative away from grazing incidence).  False means "unknown": run the ray query.
+#ifndef LRT_GRID_STEPS
+#define LRT_GRID_STEPS 4
+#endif
 DEV bool segment_proven_empty(const DDistGrid &g, V3 o, V3 d, float maxt) {
     if (!g.enabled || !(maxt < 1e30f)) return false;
-    float len = __builtin_sqrtf(dot(d, d));
-    float remaining = maxt * len * 1.01f, inv_len = 1.f / len;
+    float len = __builtin_amdgcn_sqrtf(dot(d, d));                       // hardware sqrt / rcp (1 ulp): inside the margins
+    float remaining = maxt * len * 1.01f, inv_len = __builtin_amdgcn_rcpf(len);
     V3 p = o;
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < LRT_GRID_STEPS; ++k) {
         float lb = dist_grid_lower_bound(g, p);
         if (remaining < lb) return true;
         if (!(lb > .5f * g.cell)) return false;

@@ -307,6 +307,10 @@ DEV bool volpath_iteration(const DScene &sc, const DRenderParams &rp, PathState 
         mei = medium_sample_interaction(M, ray, rng.next(), channel);
         if (mei.valid()) ray.maxt = mei.t;
         if (!proven_empty) { Hit h = tr.closest(ray); si = compute_si(sc, ray, h); }   // else: no surface within mei.t (look-ahead of the previous trip)
+#ifdef LRT_EXPERIMENT
+        if (!proven_empty && (rp.profile & 0x10000u)) { Ray r2 = ray; r2.o.x += 1e-30f; Hit h = tr.closest(r2); if (h.t == -1.f) si.t = 0.f; }
+        if (!proven_empty && (rp.profile & 0x20000u)) { Ray r2 = ray; r2.o.x += 1e-30f; Hit h; h.prim = si.valid ? si.prim : 0xffffffffu; h.t = si.t; h.u = si.uv.x; h.v = si.uv.y; SI s2 = compute_si(sc, r2, h); if (s2.t == -1.f) si.t = 0.f; }
+#endif
         if (si.t < mei.t) mei.t = kInf;
         if (M.has_spectral_extinction) {
             float t = fmin_(mei.t, si.t) - mei.mint;
@@ -430,6 +434,15 @@ DEV bool volpath_iteration(const DScene &sc, const DRenderParams &rp, PathState 
     // inside a medium the next free-flight distance is known, so the distance field may already prove that the segment
     // reaches no surface: such paths are queued separately and skip the ray query.
     uint32_t nohit = 0;
+#ifdef LRT_EXPERIMENT
+    if (active && (rp.profile & 0x40000u) && medium >= 0 && sc.grid.enabled) {
+        PCG32 pk = rng; (void) pk.next();
+        const DMedium M = sc.media[medium];
+        Ray r2 = ray; r2.o.x += 1e-30f;
+        MI m2 = medium_sample_interaction(M, r2, pk.next(), channel);
+        if (m2.valid() && segment_proven_empty(sc.grid, r2.o, r2.d, m2.t) && m2.t == -1.f) nohit = PF_NOHIT;
+    }
+#endif
     if (active) {
         PCG32 pk = rng;
         bool a2 = any_nonzero(throughput);
@@ -578,8 +591,9 @@ k_render(DScene sc, DRenderParams rp, DLdsInfo li, DPathStreams q0, DPathStreams
          const uint32_t *__restrict__ pixel_list, uint64_t lane_begin, float *__restrict__ film, float *__restrict__ sample_out, uint64_t sample_base) {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ uint32_t s_in[3], s_out[3], s_ticket, s_fresh;
-    __shared__ unsigned long long s_fresh_base;
+    __shared__ unsigned long long s_fresh_base, s_prof[8];
     const uint32_t tid = threadIdx.x, lane_in_wave = tid & 63u;
+    if (tid < 8) s_prof[tid] = 0;
     LdsScene L{};
     if (LDS_BVH) {
         const uint4 *src = li.blob; uint4 *dst = reinterpret_cast<uint4 *>(smem);
@@ -631,6 +645,17 @@ k_render(DScene sc, DRenderParams rp, DLdsInfo li, DPathStreams q0, DPathStreams
                 had_path = i < fresh;
                 if (had_path) s = generate_camera_path(sc, rp, pixel_list, lane_begin + fresh_base + i);
             }
+#ifdef LRT_EXPERIMENT
+            const PathState s_saved = s;
+            if (rp.profile & 0x1000u) {            // machinery only: every path lives 4 (or 3) trips, no integrator work
+                if (had_path) {
+                    uint32_t depth = (s.flags & PF_DEPTH_MASK) + 1u;
+                    uint32_t h = (s.lane * 2654435761u + depth * 40503u) >> 28;
+                    s.flags = (s.flags & ~(PF_DEPTH_MASK | PF_MEDIUM_MASK | PF_NOHIT)) | depth | (h < 6 ? (1u << PF_MEDIUM_SHIFT) | PF_NOHIT : (h < 12 ? (1u << PF_MEDIUM_SHIFT) : 0u));
+                    alive = depth < ((rp.profile & 0x2000u) ? 3u : 4u); n_trips += 1;
+                }
+            } else
+#endif
             if (had_path) {
                 PCG32 rng; rng.state = s.rng_state; rng.inc = lane_rng_inc(rp.seed_value, s.lane);
                 if (INTEGRATOR == LRT_INTEGRATOR_PATH) alive = LDS_BVH ? path_iteration(sc, rp, s, rng, tr_lds, n_shadow) : path_iteration(sc, rp, s, rng, tr_glb, n_shadow);
@@ -638,16 +663,32 @@ k_render(DScene sc, DRenderParams rp, DLdsInfo li, DPathStreams q0, DPathStreams
                 s.rng_state = rng.state;
                 n_trips += 1;
             }
+#ifdef LRT_EXPERIMENT
+            // cost attribution: run the trip of the selected tile kinds a second time on a copy (result discarded)
+            {
+                const int kind = t < ta ? 0 : (t < ta + tc ? 1 : (t < ta + tc + tb ? 2 : 3));
+                if ((rp.profile >> (8 + kind)) & 1u) {
+                    PathState s2 = s_saved; bool alive2 = false; uint32_t d0 = 0, d1 = 0;
+                    if (had_path) {
+                        PCG32 rng; rng.state = s2.rng_state; rng.inc = lane_rng_inc(rp.seed_value, s2.lane);
+                        if (INTEGRATOR == LRT_INTEGRATOR_PATH) alive2 = LDS_BVH ? path_iteration(sc, rp, s2, rng, tr_lds, d0) : path_iteration(sc, rp, s2, rng, tr_glb, d0);
+                        else alive2 = LDS_BVH ? volpath_iteration(sc, rp, s2, rng, tr_lds, d0, d1) : volpath_iteration(sc, rp, s2, rng, tr_glb, d0, d1);
+                    }
+                    if (alive2 && s2.flags == 0xdeadbeefu) s.res.x += s2.res.x;
+                }
+            }
+#endif
             retire_and_compact_wave(sc, rp, had_path, alive, s, film, sample_out, sample_base, qout, P, s_out);
             if ((rp.profile & 1u) && lane_in_wave == 0) {
                 const int region = t < ta ? 0 : (t < ta + tc ? 1 : (t < ta + tc + tb ? 2 : 3));
-                atomicAdd(&cnt->prof_cycles[region], wall_clock64() - t_begin); atomicAdd(&cnt->prof_tiles[region], 1ull);
+                atomicAdd(&s_prof[region], wall_clock64() - t_begin); atomicAdd(&s_prof[4 + region], 1ull);
             }
         }
         __syncthreads();
         if (tid == 0) { s_in[0] = s_out[0]; s_in[1] = s_out[1]; s_in[2] = s_out[2]; }
         const DPathStreams tmp = qin; qin = qout; qout = tmp;
     }
+    if ((rp.profile & 1u) && tid < 8) { if (tid < 4) atomicAdd(&cnt->prof_cycles[tid], s_prof[tid]); else atomicAdd(&cnt->prof_tiles[tid - 4], s_prof[tid]); }
     n_trips += n_extra;
     for (int off = 32; off > 0; off >>= 1) {
         n_shadow += __shfl_down(n_shadow, off); n_trips += __shfl_down(n_trips, off); n_loaded += __shfl_down(n_loaded, off);
