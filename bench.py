@@ -11,7 +11,7 @@ Prints ONE JSON line on rank 0 (contract: see the task statement).
 """
 import argparse
 import json
-import os
+import glob, os
 import sys
 import time
 
@@ -100,15 +100,24 @@ def main():
         dt = float(t.item())
     value = n_samples * a.steps / dt / 1e6
 
-    # ---- roofline of the dominant kernel (k_iterate), this rank's launches.  Algorithmic bytes per
-    # launch: every queued path record is read once (88 B) and every surviving one written once (88 B);
-    # summed over a render: 88 * (2 * n_records - n_samples_rank); plus 4*C bytes per pixel of film.
-    # n_records <= n_iter: loop trips the look-ahead retires early move no record.
+    # ---- roofline of the dominant kernel (k_render: ONE launch per step), this rank's launch.  Algorithmic bytes per
+    # launch: every queued path record is written once and read once (88 B each way; fresh camera paths run their first
+    # trip in registers and loop trips the look-ahead retires early move no record, so n_records <= n_iter - n_samples),
+    # plus 4*C bytes per pixel of film.  Duration: HIP events around the launch on the library's stream (kernel_ms).
     n_rank = st["n_samples"]
-    alg_bytes = STATE_BYTES * (2.0 * records - n_rank * a.steps) + 4.0 * C * w * h * a.steps / max(world, 1)
+    alg_bytes = 2.0 * STATE_BYTES * records + 4.0 * C * w * h * a.steps / max(world, 1)
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+    # HBM traffic per launch from the PMC passes of the same workload (scripts/profile_bench.sh -> profiles/*traffic.json)
+    traffic = None
+    workload = f"C3 Liver-SingleMesh {a.integrator} {w}x{h} {a.spp} spp max_depth 12 (homogeneous medium, isotropic phase, envmap)"
+    for tf in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic*.json"))):
+        try:
+            tj = json.load(open(tf))
+            if tj.get("workload") == workload and world == 1: traffic = tj["traffic_bytes_per_launch"]
+        except Exception:
+            pass
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "kernel": "lrt::k_render<%d, 1024, true>" % (0 if a.integrator == "path" else 1),
                 "launches_per_step": launches / a.steps, "avg_launch_ms": kern_ms / max(launches, 1),
                 "alg_bytes_per_launch": alg_bytes / max(launches, 1), "iterations_per_sample": iters / (n_rank * a.steps),
@@ -117,7 +126,7 @@ def main():
     out = {"metric": "Msamples/s", "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": a.steps,
            "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
            "vs_baseline": None, "dtype": "f32", "data": "reference scene files (scene.xml, liver2.obj, tissue_n.png, cavidade_latitude.exr)",
-           "config": {"workload": f"C3 Liver-SingleMesh {a.integrator} {w}x{h} {a.spp} spp max_depth 12 (homogeneous medium, isotropic phase, envmap)",
+           "config": {"workload": workload,
                       "width": w, "height": h, "spp": a.spp, "samples_per_step": n_samples,
                       "parallelism": "1 GPU" if world == 1 else f"32x32 pixel tiles over {world} GPUs + RCCL film all-reduce"},
            "roofline": roofline}

@@ -204,7 +204,7 @@ DEV float dist_grid_lower_bound(const DDistGrid &g, V3 p) {
 // distance field.  Margins: 1 % on the segment length, every advance counted 0.5 % short (f32 error of the
 // Moller-Trumbore t is ~1e-6 relative away from grazing incidence).  False means "unknown": run the ray query.
 #ifndef LRT_GRID_STEPS
-#define LRT_GRID_STEPS 4
+#define LRT_GRID_STEPS 3
 #endif
 DEV bool segment_proven_empty(const DDistGrid &g, V3 o, V3 d, float maxt) {
     if (!g.enabled || !(maxt < 1e30f)) return false;

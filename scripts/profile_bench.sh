@@ -13,5 +13,5 @@ for pass in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY
   name=$(echo $pass | tr ' ' '_' | cut -c1-40)
   rocprofv3 --pmc $pass --output-format csv -d $OUT/pmc_$name -- python3 bench.py --no-cpu-baseline "$@" > $OUT/bench_pmc_$name.log 2>&1 || echo "pmc pass failed: $pass" >> $OUT/errors.log
 done
-python3 scripts/summarize_prof.py $OUT > $OUT/summary.txt 2>&1 || true
-cat $OUT/summary.txt | head -80
+python3 scripts/summarize_prof.py $OUT "$@" > $OUT/summary.txt 2>&1 || true
+cat $OUT/summary.txt

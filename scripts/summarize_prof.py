@@ -1,17 +1,47 @@
-"""Summarise a rocprofv3 output directory produced by scripts/profile_bench.sh."""
-import csv, glob, os, sys, collections
+"""Summarise a rocprofv3 output directory produced by scripts/profile_bench.sh.
+Prints the kernel-trace stats table, the PMC counters of this library's kernels (per dispatch), derived figures for the
+render kernel, and writes <out>/traffic.json (HBM bytes per launch of the render kernel, corrected as
+MI355X_MICROARCH.md "HBM" prescribes: FETCH_SIZE x2 on gfx950 for 16-B-per-lane streaming reads, WRITE_SIZE as is;
+both counters are in KiB)."""
+import csv, glob, json, os, sys, collections
 out = sys.argv[1]
 def find(pattern):
     return sorted(glob.glob(os.path.join(out, "**", pattern), recursive=True))
 for f in find("*kernel_stats.csv"):
-    print("== kernel stats:", os.path.relpath(f, out))
+    print("== kernel stats (rocprofv3 --kernel-trace --stats):", os.path.relpath(f, out))
     for i, row in enumerate(csv.reader(open(f))):
-        if i < 12: print("  ", ", ".join(row))
+        if i < 10: print("  ", ", ".join(row))
 agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.defaultdict(lambda: collections.defaultdict(int))
 for f in find("*counter_collection.csv"):
     for row in csv.DictReader(open(f)):
-        k = row.get("Kernel_Name", "?").split("(")[0][:60]; c = row.get("Counter_Name"); v = float(row.get("Counter_Value", 0) or 0)
+        name = row.get("Kernel_Name", "?")
+        if "lrt::" not in name: continue
+        k = name.split("(")[0][:70]; c = row.get("Counter_Name"); v = float(row.get("Counter_Value", 0) or 0)
         agg[k][c] += v; cnt[k][c] += 1
 for k in agg:
-    print("== counters (sum over dispatches):", k)
-    for c in sorted(agg[k]): print(f"   {c:32s} {agg[k][c]:.6g}   (dispatches {cnt[k][c]})")
+    print("== counters, per dispatch (mean over dispatches):", k)
+    for c in sorted(agg[k]): print(f"   {c:32s} {agg[k][c] / max(cnt[k][c], 1):.6g}   (dispatches {cnt[k][c]})")
+for k in agg:
+    if "k_render" not in k: continue
+    a = {c: agg[k][c] / max(cnt[k][c], 1) for c in agg[k]}
+    print("== derived,", k)
+    if "GRBM_GUI_ACTIVE" in a and "SQ_ACTIVE_INST_VALU" in a:
+        cyc = a["GRBM_GUI_ACTIVE"] / 8.0                      # summed over the 8 XCDs
+        print(f"   GPU-active cycles {cyc:.4g}; VALU busy {a['SQ_ACTIVE_INST_VALU'] / (cyc * 1024 / 4):.1%} of SIMD quad-cycles (256 CUs x 4 SIMDs)")
+    if "SQ_THREAD_CYCLES_VALU" in a and "SQ_ACTIVE_INST_VALU" in a:
+        print(f"   VALU lane utilisation {a['SQ_THREAD_CYCLES_VALU'] / (a['SQ_ACTIVE_INST_VALU'] * 64):.1%}")
+    if "SQ_WAIT_ANY" in a and "SQ_WAVE_CYCLES" in a:
+        print(f"   wave cycles waiting {a['SQ_WAIT_ANY'] / a['SQ_WAVE_CYCLES']:.1%}")
+    if "FETCH_SIZE" in a and "WRITE_SIZE" in a:
+        rd, wr = a["FETCH_SIZE"] * 1024 * 2, a["WRITE_SIZE"] * 1024
+        print(f"   HBM traffic per launch: read {rd / 1e9:.2f} GB (FETCH_SIZE x2), write {wr / 1e9:.2f} GB, total {(rd + wr) / 1e9:.2f} GB")
+        workload = None
+        try:
+            line = [l for l in open(os.path.join(out, "bench_trace.log")) if l.startswith("{")][-1]
+            workload = json.loads(line)["config"]["workload"]
+        except Exception:
+            pass
+        json.dump({"kernel": k, "workload": workload, "read_bytes_per_launch": rd, "write_bytes_per_launch": wr,
+                   "traffic_bytes_per_launch": rd + wr, "bench_args": sys.argv[2:],
+                   "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), KiB; FETCH_SIZE doubled (gfx950 correction)"},
+                  open(os.path.join(out, "traffic.json"), "w"), indent=1)
