@@ -271,6 +271,35 @@ def test_full_size_c3_properties(mi):
     assert film_close(a, raw).all()
 
 
+# ------------------------------------------------- kernel variants and accelerators
+@pytest.mark.parametrize("env", [dict(LRT_NO_LDS_BVH="1"), dict(LRT_NO_DIST_GRID="1"), dict(LRT_LDS_BLOCK="512"),
+                                 dict(LRT_NO_NEE_REJECT="1"), dict(LRT_POOL="64"), dict(LRT_DIST_GRID_RES="24")])
+def test_kernel_variants_bit_exact(mi, orc, monkeypatch, env):
+    """Every build-time decision of the device scene (BVH in LDS or in global memory, distance-field look-ahead, exact NEE
+    rejection, pool size, workgroup size) changes speed only: lanes stay bit-identical to the oracle."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    sc = mi.load_file(LIVER_XML, integrator="volpath", spp=16, res_width=256, res_height=144)
+    o = orc.OrcScene(sc)
+    assert_lanes_equal(sc, o, 0, 256 * 144 * 16)
+    st = sc.stats()
+    assert st["n_records"] <= st["n_iter"] and st["n_launches"] == 1
+    sc = mi.load_dict(mi.cornell_box())
+    assert_lanes_equal(sc, orc.OrcScene(sc), center_lane(sc, 16), 1 << 14, spp=16, integrator="volpath")
+    assert_lanes_equal(sc, orc.OrcScene(sc), center_lane(sc, 16), 1 << 14, spp=16)
+
+
+def test_lookahead_is_invisible_in_statistics(mi, monkeypatch):
+    """The look-ahead retires trips early and skips ray queries, but n_iter / n_shadow count what the reference's loop does."""
+    a = mi.load_file(LIVER_XML, integrator="volpath", spp=8, res_width=320, res_height=180)
+    ia, ra = a.render(return_raw=True); sa = a.stats()
+    monkeypatch.setenv("LRT_NO_DIST_GRID", "1"); monkeypatch.setenv("LRT_NO_LDS_BVH", "1")
+    b = mi.load_file(LIVER_XML, integrator="volpath", spp=8, res_width=320, res_height=180)
+    ib, rb = b.render(return_raw=True); sb = b.stats()
+    assert sa["n_iter"] == sb["n_iter"] and sa["n_shadow"] == sb["n_shadow"] and sa["n_samples"] == sb["n_samples"]
+    assert film_close(ra, rb).all()
+
+
 # -------------------------------------------------------------------- error paths
 def test_error_reporting(mi, cornell):
     with pytest.raises(RuntimeError, match="tile_rank"):
