@@ -33,7 +33,7 @@ struct DeviceScene {
     // wavefront workspace
     uint32_t capacity = 0;
     DPathStreams q[2]{};
-    float4 *dl[2] = { nullptr, nullptr }; float4 *L_buf = nullptr; uint32_t prb_capacity = 0;   // PRB: delta_L streams, primal radiance
+    float4 *dl[2] = { nullptr, nullptr }; float4 *L_buf = nullptr; uint32_t prb_capacity = 0; uint64_t l_buf_lanes = 0;   // PRB: delta_L streams, primal radiance
     double *d_grads = nullptr; float *wfilm = nullptr; size_t wfilm_floats = 0; float *grad_image = nullptr; size_t grad_floats = 0;
     DCounters *counters = nullptr;
     DCounters *h_counters = nullptr;       // pinned
@@ -205,6 +205,8 @@ DeviceScene *device_scene_create(const lrt_scene_desc &d, int device) {
             HIP_CHECK(hipFuncSetAttribute((const void *) k_render<LRT_INTEGRATOR_VOLPATH, 1024, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) total));
             HIP_CHECK(hipFuncSetAttribute((const void *) k_render<LRT_INTEGRATOR_PATH, 512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) total));
             HIP_CHECK(hipFuncSetAttribute((const void *) k_render<LRT_INTEGRATOR_VOLPATH, 512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) total));
+            HIP_CHECK(hipFuncSetAttribute((const void *) k_render_prb<false, 1024, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) total));
+            HIP_CHECK(hipFuncSetAttribute((const void *) k_render_prb<true, 1024, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) total));
             D->use_lds = true;
         }
     }
@@ -395,12 +397,13 @@ static void ensure_pixel_list(DeviceScene *D, const ResolvedOpts &O) {
     D->pixel_list_rank = O.tile_rank; D->pixel_list_count = O.tile_count; D->n_owned_pixels = (uint32_t) px.size();
 }
 
-static void ensure_prb_workspace(DeviceScene *D, uint32_t capacity) {
-    if (D->prb_capacity >= capacity) return;
-    for (int k = 0; k < 2; ++k) { HIP_CHECK(hipMalloc((void **) &D->dl[k], (size_t) capacity * 16)); D->track(D->dl[k]); }
-    HIP_CHECK(hipMalloc((void **) &D->L_buf, (size_t) capacity * 16)); D->track(D->L_buf);
+static void ensure_prb_workspace(DeviceScene *D, uint32_t records, uint64_t l_buf_lanes) {
+    if (D->prb_capacity < records) {
+        for (int k = 0; k < 2; ++k) { HIP_CHECK(hipMalloc((void **) &D->dl[k], (size_t) records * 16)); D->track(D->dl[k]); }
+        D->prb_capacity = records;
+    }
+    if (D->l_buf_lanes < l_buf_lanes) { HIP_CHECK(hipMalloc((void **) &D->L_buf, (size_t) l_buf_lanes * 16)); D->track(D->L_buf); D->l_buf_lanes = l_buf_lanes; }
     if (!D->d_grads) { HIP_CHECK(hipMalloc((void **) &D->d_grads, 7 * sizeof(double))); D->track(D->d_grads); }
-    D->prb_capacity = capacity;
 }
 
 static DRenderParams make_params(const lrt_scene_desc &d, const ResolvedOpts &O, uint64_t n_lanes) {
@@ -413,35 +416,6 @@ static DRenderParams make_params(const lrt_scene_desc &d, const ResolvedOpts &O,
 }
 
 struct LaunchLog { std::vector<std::pair<hipEvent_t, hipEvent_t>> launches; std::vector<uint32_t> sizes; std::vector<std::array<uint32_t, 3>> regions; unsigned long long n_records = 0; size_t ev = 0; uint64_t n_iter = 0; };
-
-// Drains one chunk of `n` freshly generated paths sitting in q[0]: launches `iterate(cur, n)` until the queue is empty.
-template <typename Iterate>
-static void drain_chunk(DeviceScene *D, uint32_t n, LaunchLog &log, bool count_iter, Iterate iterate) {
-    hipStream_t st = D->stream;
-    int cur = 0;
-    while (n > 0) {
-        HIP_CHECK(hipMemsetAsync(&D->counters->n_out, 0, 2 * sizeof(uint32_t), st));      // n_out and the tile ticket
-        hipEvent_t a = get_event(D, log.ev++), b = get_event(D, log.ev++);
-        HIP_CHECK(hipEventRecord(a, st));
-        iterate(cur, n);
-        HIP_CHECK(hipEventRecord(b, st));
-        log.launches.emplace_back(a, b); log.sizes.push_back(n);
-        HIP_CHECK(hipMemcpyAsync(D->h_counters, D->counters, sizeof(DCounters), hipMemcpyDeviceToHost, st));
-        HIP_CHECK(hipStreamSynchronize(st));
-        if (count_iter) log.n_iter += n;
-        n = D->h_counters->n_out;
-        cur ^= 1;
-        if (getenv("LRT_DEBUG_STATE") && n > 0) {      // developer aid: dump the first surviving path record
-            float4 a4, b4, c4, d4, e4;
-            (void) hipMemcpy(&a4, D->q[cur].o_maxt, 16, hipMemcpyDeviceToHost); (void) hipMemcpy(&b4, D->q[cur].d_eta, 16, hipMemcpyDeviceToHost);
-            (void) hipMemcpy(&c4, D->q[cur].tp_pdf, 16, hipMemcpyDeviceToHost); (void) hipMemcpy(&d4, D->q[cur].res_flags, 16, hipMemcpyDeviceToHost);
-            (void) hipMemcpy(&e4, D->q[cur].lp_lane, 16, hipMemcpyDeviceToHost);
-            uint32_t fl, ln; memcpy(&fl, &d4.w, 4); memcpy(&ln, &e4.w, 4);
-            fprintf(stderr, "[lrt] n=%u o=(%g %g %g) maxt=%g d=(%g %g %g) eta=%g tp=(%g %g %g) pdf=%g res=(%g %g %g) flags=%08x lane=%u\n", n,
-                    a4.x, a4.y, a4.z, a4.w, b4.x, b4.y, b4.z, b4.w, c4.x, c4.y, c4.z, c4.w, d4.x, d4.y, d4.z, fl, ln);
-        }
-    }
-}
 
 static void finish_stats(DeviceScene *D, LaunchLog &log, hipEvent_t e_begin, hipEvent_t e_end, uint64_t n_lanes, lrt_render_stats &stats) {
     hipStream_t st = D->stream;
@@ -467,58 +441,67 @@ static void finish_stats(DeviceScene *D, LaunchLog &log, hipEvent_t e_begin, hip
     HIP_CHECK(hipEventElapsedTime(&ms, e_begin, e_end)); stats.total_ms = ms;
 }
 
-// The wavefront loop.  sample_out != nullptr: per-lane test hook for lanes [lane_begin, lane_begin + n_lanes).
+// Geometry of the persistent kernels: one 1024-thread workgroup per CU when the BVH lives in LDS, else four 256-thread
+// ones; P = paths in flight per workgroup (multiple of 64), queues of 2P records per workgroup.
+struct PoolGeometry { uint32_t n_wg, P, block; size_t smem; };
+static PoolGeometry pool_geometry(DeviceScene *D, uint64_t n_lanes) {
+    PoolGeometry g;
+    g.n_wg = D->use_lds ? (uint32_t) D->n_cus : 4u * (uint32_t) D->n_cus;
+    const uint32_t pool_max = getenv("LRT_POOL") ? std::max(64, atoi(getenv("LRT_POOL"))) : (D->use_lds ? 32768u : 8192u);
+    g.P = (uint32_t) std::min<uint64_t>(pool_max, std::max<uint64_t>(64, ((n_lanes + g.n_wg - 1) / g.n_wg + 63) / 64 * 64));
+    g.block = D->use_lds ? (uint32_t) D->lds_block : (uint32_t) LRT_BLOCK;
+    g.smem = D->use_lds ? D->lds.total_bytes : (size_t) LRT_STACK * LRT_BLOCK * sizeof(int);
+    return g;
+}
+
+template <bool ADJOINT>
+static void launch_prb(DeviceScene *D, const DRenderParams &rp, const PoolGeometry &g, const uint32_t *pixel_list, uint64_t lane_begin,
+                       float4 *L_buf, const float *grad_image, double *grads, float *film, float *sample_out) {
+    hipStream_t st = D->stream;
+    HIP_CHECK(hipMemsetAsync(&D->counters->next_lane, 0, sizeof(unsigned long long), st));
+    if (D->use_lds) k_render_prb<ADJOINT, 1024, true><<<g.n_wg, 1024, g.smem, st>>>(D->sc, rp, D->lds, D->q[0], D->q[1], D->dl[0], D->dl[1], g.P, D->counters, pixel_list, lane_begin, L_buf, grad_image, D->wfilm, grads, film, sample_out, lane_begin);
+    else k_render_prb<ADJOINT, LRT_BLOCK, false><<<g.n_wg, LRT_BLOCK, g.smem, st>>>(D->sc, rp, D->lds, D->q[0], D->q[1], D->dl[0], D->dl[1], g.P, D->counters, pixel_list, lane_begin, L_buf, grad_image, D->wfilm, grads, film, sample_out, lane_begin);
+    HIP_CHECK(hipGetLastError());
+}
+
+// One persistent launch per render (k_render / k_render_prb): per-workgroup path pools, in-kernel regeneration; see
+// kernels.h.  sample_out != nullptr: per-lane test hook for lanes [lane_begin, lane_begin + n_lanes).
 static void run_wavefront(DeviceScene *D, const lrt_scene_desc &d, const ResolvedOpts &O, uint64_t lane_begin, uint64_t n_lanes,
                           const uint32_t *pixel_list, float *film, float *sample_out, lrt_render_stats &stats) {
     hipStream_t st = D->stream;
     DRenderParams rp = make_params(d, O, n_lanes);
-    const uint32_t chunk = (uint32_t) std::min<uint64_t>(n_lanes, 1u << 23);
     const bool prb = O.integrator == LRT_INTEGRATOR_PRBVOLPATH;
-    // render kernel geometry: one 1024-thread workgroup per CU when the BVH lives in LDS, else four 256-thread ones;
-    // P = paths in flight per workgroup (multiple of 64), queues of 2P records per workgroup
-    const uint32_t n_wg = D->use_lds ? (uint32_t) D->n_cus : 4u * (uint32_t) D->n_cus;
-    const uint32_t pool_max = getenv("LRT_POOL") ? std::max(64, atoi(getenv("LRT_POOL"))) : (D->use_lds ? 32768u : 8192u);
-    const uint32_t P = (uint32_t) std::min<uint64_t>(pool_max, ((n_lanes + n_wg - 1) / n_wg + 63) / 64 * 64 + (n_lanes ? 0 : 64));
-    ensure_workspace(D, prb ? std::max<uint32_t>(chunk, 1) : (uint32_t) std::min<uint64_t>((uint64_t) n_wg * 2u * P, 0xffffffffull));
-    if (prb) ensure_prb_workspace(D, std::max<uint32_t>(chunk, 1));
+    PoolGeometry g = pool_geometry(D, n_lanes);
+    if (prb && D->use_lds) g.block = 1024;
+    const uint32_t records = (uint32_t) std::min<uint64_t>((uint64_t) g.n_wg * 2u * g.P, 0xffffffffull);
+    ensure_workspace(D, records);
+    if (prb) ensure_prb_workspace(D, records, 0);
     HIP_CHECK(hipMemsetAsync(D->counters, 0, sizeof(DCounters), st));
     LaunchLog log;
     hipEvent_t e_begin = get_event(D, log.ev++), e_end = get_event(D, log.ev++);
     HIP_CHECK(hipEventRecord(e_begin, st));
     // path.cpp:103-104 returns before the loop when max_depth == 0: that launch only retires the lanes
     const bool count_iter = !(O.integrator == LRT_INTEGRATOR_PATH && O.max_depth == 0);
-    if (prb) {
-        for (uint64_t base = 0; base < n_lanes; base += chunk) {
-            uint32_t n = (uint32_t) std::min<uint64_t>(chunk, n_lanes - base);
-            uint32_t grid0 = (n + LRT_BLOCK - 1) / LRT_BLOCK;
-            k_raygen_prb<false><<<grid0, LRT_BLOCK, 0, st>>>(D->sc, rp, D->q[0], D->dl[0], pixel_list, lane_begin + base, n, nullptr, nullptr, nullptr);
-            drain_chunk(D, n, log, count_iter, [&](int cur, uint32_t m) {
-                uint32_t grid = (m + LRT_BLOCK - 1) / LRT_BLOCK;
-                k_iterate_prb<false><<<grid, LRT_BLOCK, 0, st>>>(D->sc, rp, D->q[cur], D->q[cur ^ 1], D->dl[cur], D->dl[cur ^ 1], D->counters, m, nullptr, nullptr, film, sample_out, lane_begin);
-            });
-        }
-        finish_stats(D, log, e_begin, e_end, n_lanes, stats);
-        return;
-    }
-    // One persistent launch (k_render): per-workgroup path pools, in-kernel regeneration; see kernels.h.
     const bool isp = O.integrator == LRT_INTEGRATOR_PATH;
     hipEvent_t a = get_event(D, log.ev++), b = get_event(D, log.ev++);
     HIP_CHECK(hipEventRecord(a, st));
-    #define LRT_LAUNCH(I, BS, LDSB, SMEM) k_render<I, BS, LDSB><<<n_wg, BS, SMEM, st>>>(D->sc, rp, D->lds, D->q[0], D->q[1], P, D->counters, pixel_list, lane_begin, film, sample_out, lane_begin)
-    if (D->use_lds) {
-        if (D->lds_block == 512) { if (isp) LRT_LAUNCH(LRT_INTEGRATOR_PATH, 512, true, D->lds.total_bytes); else LRT_LAUNCH(LRT_INTEGRATOR_VOLPATH, 512, true, D->lds.total_bytes); }
-        else { if (isp) LRT_LAUNCH(LRT_INTEGRATOR_PATH, 1024, true, D->lds.total_bytes); else LRT_LAUNCH(LRT_INTEGRATOR_VOLPATH, 1024, true, D->lds.total_bytes); }
-    } else {
-        if (isp) LRT_LAUNCH(LRT_INTEGRATOR_PATH, LRT_BLOCK, false, LRT_STACK * LRT_BLOCK * sizeof(int)); else LRT_LAUNCH(LRT_INTEGRATOR_VOLPATH, LRT_BLOCK, false, LRT_STACK * LRT_BLOCK * sizeof(int));
+    if (prb) launch_prb<false>(D, rp, g, pixel_list, lane_begin, nullptr, nullptr, nullptr, film, sample_out);
+    else {
+        #define LRT_LAUNCH(I, BS, LDSB) k_render<I, BS, LDSB><<<g.n_wg, BS, g.smem, st>>>(D->sc, rp, D->lds, D->q[0], D->q[1], g.P, D->counters, pixel_list, lane_begin, film, sample_out, lane_begin)
+        if (D->use_lds) {
+            if (D->lds_block == 512) { if (isp) LRT_LAUNCH(LRT_INTEGRATOR_PATH, 512, true); else LRT_LAUNCH(LRT_INTEGRATOR_VOLPATH, 512, true); }
+            else { if (isp) LRT_LAUNCH(LRT_INTEGRATOR_PATH, 1024, true); else LRT_LAUNCH(LRT_INTEGRATOR_VOLPATH, 1024, true); }
+        } else {
+            if (isp) LRT_LAUNCH(LRT_INTEGRATOR_PATH, LRT_BLOCK, false); else LRT_LAUNCH(LRT_INTEGRATOR_VOLPATH, LRT_BLOCK, false);
+        }
+        #undef LRT_LAUNCH
+        HIP_CHECK(hipGetLastError());
     }
-    #undef LRT_LAUNCH
-    HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipEventRecord(b, st));
     log.launches.emplace_back(a, b); log.sizes.push_back(0);
     HIP_CHECK(hipMemcpyAsync(D->h_counters, D->counters, sizeof(DCounters), hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
     log.n_iter = count_iter ? D->h_counters->n_iter : 0;
-    log.sizes[0] = (uint32_t) std::min<unsigned long long>(D->h_counters->n_records, 0xffffffffull);
     log.n_records = D->h_counters->n_records;
     finish_stats(D, log, e_begin, e_end, n_lanes, stats);
 }
@@ -624,8 +607,12 @@ void device_render_backward(DeviceScene *D, const lrt_scene_desc &d, const lrt_r
     const uint64_t n_lanes = (uint64_t) D->n_owned_pixels * O.spp;
     const uint32_t *pixel_list = O.tile_count > 1 ? D->pixel_list : nullptr;
     DRenderParams rp = make_params(d, O, n_lanes);
-    const uint32_t chunk = (uint32_t) std::min<uint64_t>(std::max<uint64_t>(n_lanes, 1), 1u << 23);
-    ensure_workspace(D, chunk); ensure_prb_workspace(D, chunk);
+    // primal radiance of every lane of a pass is kept (16 B / lane); passes of at most 2^28 lanes bound that buffer to 4.3 GB
+    const uint64_t pass = std::min<uint64_t>(std::max<uint64_t>(n_lanes, 1), 1ull << 28);
+    PoolGeometry g = pool_geometry(D, pass);
+    if (D->use_lds) g.block = 1024;
+    const uint32_t records = (uint32_t) std::min<uint64_t>((uint64_t) g.n_wg * 2u * g.P, 0xffffffffull);
+    ensure_workspace(D, records); ensure_prb_workspace(D, records, pass);
     const float *g_img = grad_image;
     if (!(opts && opts->output_on_device)) {
         if (D->grad_floats < np * T) { HIP_CHECK(hipMalloc((void **) &D->grad_image, np * T * 4)); D->track(D->grad_image); D->grad_floats = np * T; }
@@ -643,18 +630,20 @@ void device_render_backward(DeviceScene *D, const lrt_scene_desc &d, const lrt_r
     LaunchLog log;
     hipEvent_t e_begin = get_event(D, log.ev++), e_end = get_event(D, log.ev++);
     HIP_CHECK(hipEventRecord(e_begin, st));
-    for (uint64_t base = 0; base < n_lanes; base += chunk) {
-        uint32_t n = (uint32_t) std::min<uint64_t>(chunk, n_lanes - base);
-        uint32_t grid0 = (n + LRT_BLOCK - 1) / LRT_BLOCK;
-        k_raygen_prb<false><<<grid0, LRT_BLOCK, 0, st>>>(D->sc, rp, D->q[0], D->dl[0], pixel_list, base, n, nullptr, nullptr, nullptr);
-        drain_chunk(D, n, log, true, [&](int cur, uint32_t m) {
-            k_iterate_prb<false><<<(m + LRT_BLOCK - 1) / LRT_BLOCK, LRT_BLOCK, 0, st>>>(D->sc, rp, D->q[cur], D->q[cur ^ 1], D->dl[cur], D->dl[cur ^ 1], D->counters, m, D->L_buf, nullptr, nullptr, nullptr, 0);
-        });
-        k_raygen_prb<true><<<grid0, LRT_BLOCK, 0, st>>>(D->sc, rp, D->q[0], D->dl[0], pixel_list, base, n, D->L_buf, g_img, D->wfilm);
-        drain_chunk(D, n, log, true, [&](int cur, uint32_t m) {
-            k_iterate_prb<true><<<(m + LRT_BLOCK - 1) / LRT_BLOCK, LRT_BLOCK, 0, st>>>(D->sc, rp, D->q[cur], D->q[cur ^ 1], D->dl[cur], D->dl[cur ^ 1], D->counters, m, nullptr, D->d_grads, nullptr, nullptr, 0);
-        });
+    for (uint64_t base = 0; base < n_lanes; base += pass) {
+        rp.n_lanes = std::min<uint64_t>(pass, n_lanes - base);
+        for (int adjoint = 0; adjoint < 2; ++adjoint) {
+            hipEvent_t a = get_event(D, log.ev++), b = get_event(D, log.ev++);
+            HIP_CHECK(hipEventRecord(a, st));
+            if (!adjoint) launch_prb<false>(D, rp, g, pixel_list, base, D->L_buf, nullptr, nullptr, nullptr, nullptr);
+            else launch_prb<true>(D, rp, g, pixel_list, base, D->L_buf, g_img, D->d_grads, nullptr, nullptr);
+            HIP_CHECK(hipEventRecord(b, st));
+            log.launches.emplace_back(a, b); log.sizes.push_back(0);
+        }
     }
+    HIP_CHECK(hipMemcpyAsync(D->h_counters, D->counters, sizeof(DCounters), hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    log.n_iter = D->h_counters->n_iter; log.n_records = D->h_counters->n_records;
     finish_stats(D, log, e_begin, e_end, n_lanes, stats);
     double h[7];
     HIP_CHECK(hipMemcpy(h, D->d_grads, sizeof(h), hipMemcpyDeviceToHost));

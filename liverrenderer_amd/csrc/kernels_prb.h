@@ -288,94 +288,127 @@ DEV V3 lane_delta_L(const DScene &sc, const DRenderParams &rp, uint32_t lane, co
     return dL;
 }
 
-// ADJOINT == false: primal PRB pass; finished lanes store L into L_buf[slot] (slot = chunk-local lane index).
-// ADJOINT == true : replay; finished lanes only retire, gradients are block-reduced and added to grads[7] (f64).
-template <bool ADJOINT>
-__global__ void __launch_bounds__(LRT_BLOCK)
-k_iterate_prb(DScene sc, DRenderParams rp, DPathStreams qin, DPathStreams qout, const float4 *__restrict__ dl_in, float4 *__restrict__ dl_out,
-              DCounters *__restrict__ cnt, uint32_t n_in, float4 *__restrict__ L_buf, double *__restrict__ grads,
-              float *__restrict__ film, float *__restrict__ sample_out, uint64_t sample_base) {
-    __shared__ int s_stack[LRT_STACK * LRT_BLOCK];
-    __shared__ uint32_t s_wave_count[LRT_BLOCK / 64];
-    __shared__ uint32_t s_base;
-    __shared__ uint32_t s_shadow;
-    __shared__ float s_grad[7];
-    const uint32_t tid = threadIdx.x, i = blockIdx.x * LRT_BLOCK + tid;
-    const uint32_t wave = tid >> 6, lane_in_wave = tid & 63u;
-    if (tid == 0) s_shadow = 0;
-    if (tid < 7) s_grad[tid] = 0.f;
-    bool alive = false;
-    PathState s; float4 dl = make_float4(0.f, 0.f, 0.f, 0.f);
-    uint32_t n_shadow = 0;
-    PrbGrads G; G.sigma_t[0] = G.sigma_t[1] = G.sigma_t[2] = G.albedo[0] = G.albedo[1] = G.albedo[2] = G.g = 0.f;
-    if (i < n_in) {
-        load_state(qin, i, s); dl = dl_in[i];
-        PCG32 rng; rng.state = s.rng_state; rng.inc = lane_rng_inc(rp.seed_value, s.lane);
-        const GlobalTracer tr{ sc, s_stack + tid };
-        alive = prb_iteration<ADJOINT>(sc, rp, s, rng, tr, n_shadow, V3(dl.x, dl.y, dl.z), G);
-        s.rng_state = rng.state;
-        if (!alive && !ADJOINT) {
-            if (L_buf) L_buf[f2u(dl.w)] = make_float4(s.res.x, s.res.y, s.res.z, (s.flags & PF_VALID) ? 1.f : 0.f);
-            else finish_path(sc, rp, film, sample_out, sample_base, s.lane, s.res, (s.flags & PF_VALID) != 0);
+// PRB passes on the persistent render kernel of kernels.h (same rounds, pools and tiles; two queue regions: in-medium
+// paths from the front, the others from the back; one extra float4 stream carries delta_L and the lane's slot).
+// ADJOINT == false: primal pass; finished lanes store L into L_buf[slot] (slot = index of the lane in this launch), or
+//                   splat into the film / sample_out when L_buf is null (lrt_render with integrator prbvolpath).
+// ADJOINT == true : replay; finished lanes only retire; the parameter gradients of a tile are summed inside the wave,
+//                   accumulated per workgroup in f64 (LDS) and added to grads[7] once at the end.
+template <bool ADJOINT, int BLOCK, bool LDS_BVH>
+__global__ void __launch_bounds__(BLOCK)
+k_render_prb(DScene sc, DRenderParams rp, DLdsInfo li, DPathStreams q0, DPathStreams q1, float4 *__restrict__ dl0, float4 *__restrict__ dl1, uint32_t P,
+             DCounters *__restrict__ cnt, const uint32_t *__restrict__ pixel_list, uint64_t lane_begin,
+             float4 *__restrict__ L_buf, const float *__restrict__ grad_image, const float *__restrict__ wfilm, double *__restrict__ grads,
+             float *__restrict__ film, float *__restrict__ sample_out, uint64_t sample_base) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ uint32_t s_in[2], s_out[2], s_ticket, s_fresh;
+    __shared__ unsigned long long s_fresh_base;
+    __shared__ double s_grad[7];
+    const uint32_t tid = threadIdx.x, lane_in_wave = tid & 63u;
+    LdsScene L{};
+    if (LDS_BVH) {
+        const uint4 *src = li.blob; uint4 *dst = reinterpret_cast<uint4 *>(smem);
+        for (uint32_t k = tid; k < li.blob_bytes / 16u; k += BLOCK) dst[k] = src[k];
+        L.nodes = reinterpret_cast<const float4 *>(smem + li.nodes_off); L.verts = reinterpret_cast<const float4 *>(smem + li.verts_off);
+        L.tris = reinterpret_cast<const uint2 *>(smem + li.tris_off); L.slot_prim = li.slot_prim;
+        L.n_faces = sc.n_faces; L.root_is_leaf = (uint32_t) sc.root_is_leaf; L.root_first = sc.root_leaf_first; L.root_count = sc.root_leaf_count;
+    }
+    const LdsTracer<BLOCK> tr_lds{ L, reinterpret_cast<uint16_t *>(smem + li.stack_off) + tid };
+    const GlobalTracer tr_glb{ sc, reinterpret_cast<int *>(smem) + tid };
+    const size_t pool = (size_t) blockIdx.x * 2u * P;
+    DPathStreams qin = offset_streams(q0, pool), qout = offset_streams(q1, pool);
+    float4 *dlin = dl0 + pool, *dlout = dl1 + pool;
+    if (tid == 0) { s_in[0] = s_in[1] = 0; }
+    if (tid < 7) s_grad[tid] = 0.0;
+    bool lanes_left = true;                                   // thread 0
+    uint32_t n_shadow = 0, n_trips = 0, n_loaded = 0;
+    for (;;) {
+        if (tid == 0) {
+            const uint32_t want = P - (s_in[0] + s_in[1]);
+            uint32_t got = 0; unsigned long long base = 0;
+            if (want && lanes_left) {
+                base = atomicAdd(&cnt->next_lane, (unsigned long long) want);
+                if (base < rp.n_lanes) got = (uint32_t) (rp.n_lanes - base < (unsigned long long) want ? rp.n_lanes - base : (unsigned long long) want);
+                lanes_left = base + want < rp.n_lanes;
+            }
+            s_fresh = got; s_fresh_base = base; s_ticket = 0; s_out[0] = s_out[1] = 0;
         }
+        __syncthreads();
+        const uint32_t n_m = s_in[0], n_s = s_in[1], fresh = s_fresh;
+        const unsigned long long fresh_base = s_fresh_base;
+        if (n_m + n_s + fresh == 0) break;
+        const uint32_t tm = (n_m + 63u) >> 6, ts = (n_s + 63u) >> 6, tf = (fresh + 63u) >> 6;
+        for (;;) {
+            uint32_t t = 0;
+            if (lane_in_wave == 0) t = atomicAdd(&s_ticket, 1u);
+            t = (uint32_t) __builtin_amdgcn_readfirstlane((int) t);
+            if (t >= tm + ts + tf) break;
+            bool had_path = false, alive = false;
+            PathState s; s.flags = 0; s.lane = 0; s.res = V3(0.f);
+            float4 dl = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (t < tm + ts) {
+                uint32_t i;
+                if (t < tm) { i = (t << 6) + lane_in_wave; had_path = i < n_m; }
+                else { i = ((t - tm) << 6) + lane_in_wave; had_path = i < n_s; i = 2u * P - 1u - i; }
+                if (had_path) { load_state(qin, i, s); dl = dlin[i]; n_loaded += 1; }
+            } else {
+                const uint32_t i = ((t - tm - ts) << 6) + lane_in_wave;
+                had_path = i < fresh;
+                if (had_path) {                                // common.py:231-309 + prbvolpath.py:113-137
+                    const unsigned long long slot = fresh_base + i;
+                    s = generate_camera_path(sc, rp, pixel_list, lane_begin + slot);
+                    s.flags = PF_SPECULAR | (s.flags & (3u << PF_CHANNEL_SHIFT));      // valid_ray = false, specular_chain = true, medium = none
+                    V3 dL(0.f);
+                    if (ADJOINT) { float4 l = L_buf[slot]; s.res = V3(l.x, l.y, l.z); dL = lane_delta_L(sc, rp, s.lane, grad_image, wfilm); }
+                    dl = make_float4(dL.x, dL.y, dL.z, u2f((uint32_t) slot));
+                }
+            }
+            PrbGrads G; G.sigma_t[0] = G.sigma_t[1] = G.sigma_t[2] = G.albedo[0] = G.albedo[1] = G.albedo[2] = G.g = 0.f;
+            if (had_path) {
+                PCG32 rng; rng.state = s.rng_state; rng.inc = lane_rng_inc(rp.seed_value, s.lane);
+                alive = LDS_BVH ? prb_iteration<ADJOINT>(sc, rp, s, rng, tr_lds, n_shadow, V3(dl.x, dl.y, dl.z), G)
+                                : prb_iteration<ADJOINT>(sc, rp, s, rng, tr_glb, n_shadow, V3(dl.x, dl.y, dl.z), G);
+                s.rng_state = rng.state;
+                n_trips += 1;
+            }
+            if (!ADJOINT) {
+                if (L_buf) { if (had_path && !alive) L_buf[f2u(dl.w)] = make_float4(s.res.x, s.res.y, s.res.z, (s.flags & PF_VALID) ? 1.f : 0.f); }
+                else finish_paths_wave(sc, rp, film, sample_out, sample_base, had_path && !alive, s.lane, s.res, (s.flags & PF_VALID) != 0);
+            } else {
+                float g[7] = { G.sigma_t[0], G.sigma_t[1], G.sigma_t[2], G.albedo[0], G.albedo[1], G.albedo[2], G.g };
+#pragma unroll
+                for (int k = 0; k < 7; ++k) {
+                    float v = g[k];
+                    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+                    if (lane_in_wave == 0 && v != 0.f) atomicAdd(&s_grad[k], (double) v);
+                }
+            }
+            // compaction: in-medium survivors to the front, the others to the back
+            const bool in_medium = (s.flags & PF_MEDIUM_MASK) != 0;
+            const unsigned long long mm = __ballot(alive && in_medium), ms = __ballot(alive && !in_medium);
+            uint32_t base = 0;
+            if (lane_in_wave < 2) { const uint32_t c = (uint32_t) __popcll(lane_in_wave == 0 ? mm : ms); if (c) base = atomicAdd(&s_out[lane_in_wave], c); }
+            const uint32_t b = __shfl(base, in_medium ? 0 : 1);
+            if (alive) {
+                const uint32_t slot = b + (uint32_t) __popcll((in_medium ? mm : ms) & ((1ull << lane_in_wave) - 1ull));
+                const uint32_t rec = in_medium ? slot : 2u * P - 1u - slot;
+                store_state(qout, rec, s); dlout[rec] = dl;
+            }
+        }
+        __syncthreads();
+        if (tid == 0) { s_in[0] = s_out[0]; s_in[1] = s_out[1]; }
+        const DPathStreams tmp = qin; qin = qout; qout = tmp;
+        float4 *tdl = dlin; dlin = dlout; dlout = tdl;
     }
-    const unsigned long long m = __ballot(alive);
-    const uint32_t wcount = (uint32_t) __popcll(m);
-    const uint32_t wprefix = (uint32_t) __popcll(m & ((1ull << lane_in_wave) - 1ull));
-    if (lane_in_wave == 0) s_wave_count[wave] = wcount;
-    for (int off = 32; off > 0; off >>= 1) n_shadow += __shfl_down(n_shadow, off);
-    auto wave_sum = [&](float v) { for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off); return v; };
-    float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f, g4 = 0.f, g5 = 0.f, g6 = 0.f;
-    if (ADJOINT) {
-        g0 = wave_sum(G.sigma_t[0]); g1 = wave_sum(G.sigma_t[1]); g2 = wave_sum(G.sigma_t[2]);
-        g3 = wave_sum(G.albedo[0]); g4 = wave_sum(G.albedo[1]); g5 = wave_sum(G.albedo[2]); g6 = wave_sum(G.g);
+    if (ADJOINT && tid < 7 && s_grad[tid] != 0.0) atomicAdd(&grads[tid], s_grad[tid]);
+    for (int off = 32; off > 0; off >>= 1) {
+        n_shadow += __shfl_down(n_shadow, off); n_trips += __shfl_down(n_trips, off); n_loaded += __shfl_down(n_loaded, off);
     }
-    __syncthreads();
-    if (lane_in_wave == 0 && n_shadow) atomicAdd(&s_shadow, n_shadow);
-    if (ADJOINT && lane_in_wave == 0) {
-        atomicAdd(&s_grad[0], g0); atomicAdd(&s_grad[1], g1); atomicAdd(&s_grad[2], g2); atomicAdd(&s_grad[3], g3);
-        atomicAdd(&s_grad[4], g4); atomicAdd(&s_grad[5], g5); atomicAdd(&s_grad[6], g6);
+    if (lane_in_wave == 0) {
+        if (n_shadow) atomicAdd(&cnt->n_shadow, (unsigned long long) n_shadow);
+        if (n_trips) atomicAdd(&cnt->n_iter, (unsigned long long) n_trips);
+        if (n_loaded) atomicAdd(&cnt->n_records, (unsigned long long) n_loaded);
     }
-    if (tid == 0) {
-        uint32_t total = 0;
-        for (int w = 0; w < LRT_BLOCK / 64; ++w) total += s_wave_count[w];
-        s_base = total ? atomicAdd(&cnt->n_out, total) : 0u;
-    }
-    __syncthreads();
-    if (alive) {
-        uint32_t slot = s_base + wprefix;
-        for (uint32_t w = 0; w < wave; ++w) slot += s_wave_count[w];
-        store_state(qout, slot, s); dl_out[slot] = dl;
-    }
-    if (tid == 0 && s_shadow) atomicAdd(&cnt->n_shadow, (unsigned long long) s_shadow);
-    if (ADJOINT && tid < 7 && s_grad[tid] != 0.f) atomicAdd(&grads[tid], (double) s_grad[tid]);
-}
-
-// Ray generation for the PRB passes (common.py:231-309 + prbvolpath.py:113-137).
-template <bool ADJOINT>
-__global__ void __launch_bounds__(LRT_BLOCK)
-k_raygen_prb(DScene sc, DRenderParams rp, DPathStreams q, float4 *__restrict__ dl_out, const uint32_t *__restrict__ pixel_list,
-             uint64_t lane_base, uint32_t n, const float4 *__restrict__ L_buf, const float *__restrict__ grad_image, const float *__restrict__ wfilm) {
-    uint32_t i = blockIdx.x * LRT_BLOCK + threadIdx.x;
-    if (i >= n) return;
-    uint64_t j = lane_base + i;
-    uint32_t lane;
-    if (pixel_list) { uint32_t pj = (uint32_t) (j / rp.spp); lane = pixel_list[pj] * rp.spp + (uint32_t) (j - (uint64_t) pj * rp.spp); }
-    else lane = (uint32_t) j;
-    PCG32 rng = lane_rng_fresh(rp.seed_value, lane);
-    int px, py; lane_to_pixel(sc, rp, lane, &px, &py);
-    float jx = rng.next(), jy = rng.next();
-    float spx = (float) px + jx, spy = (float) py + jy;
-    Ray ray = camera_ray(sc, fma_(spx, sc.film.scale_x, sc.film.offset_x), fma_(spy, sc.film.scale_y, sc.film.offset_y));
-    PathState s;
-    s.o = ray.o; s.d = ray.d; s.maxt = ray.maxt; s.eta = 1.f; s.tp = V3(1.f); s.lp = V3(0.f); s.last_pdf = 1.f; s.lane = lane;
-    uint32_t channel = min((uint32_t) (3.f * rng.next()), 2u);
-    s.flags = PF_SPECULAR | (channel << PF_CHANNEL_SHIFT);      // valid_ray = false, specular_chain = true, medium = none
-    s.rng_state = rng.state;
-    V3 dL(0.f); s.res = V3(0.f);
-    if (ADJOINT) { float4 l = L_buf[i]; s.res = V3(l.x, l.y, l.z); dL = lane_delta_L(sc, rp, lane, grad_image, wfilm); }
-    store_state(q, i, s);
-    dl_out[i] = make_float4(dL.x, dL.y, dL.z, u2f(i));
 }
 
 } // namespace lrt
