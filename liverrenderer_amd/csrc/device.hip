@@ -39,6 +39,7 @@ struct DeviceScene {
     DCounters *h_counters = nullptr;       // pinned
     float *film = nullptr; size_t film_floats = 0;
     float *image = nullptr; size_t image_floats = 0;
+    uint32_t *pixel_slot = nullptr;         // inverse of pixel_list (pixel -> index in the list), tile-sharded renders
     uint32_t *pixel_list = nullptr; uint32_t pixel_list_rank = 0xffffffffu, pixel_list_count = 0, n_owned_pixels = 0;
     std::vector<hipEvent_t> ev_pool;
     std::vector<DMedium> h_media; DMedium *d_media = nullptr;
@@ -394,6 +395,9 @@ static void ensure_pixel_list(DeviceScene *D, const ResolvedOpts &O) {
             for (uint32_t x = x0; x < std::min<uint32_t>(x0 + 32, F.width); ++x) px.push_back(y * F.width + x);
     }
     D->pixel_list = D->track(dev_upload(px.data(), px.size(), D->stream));
+    std::vector<uint32_t> inv((size_t) F.width * F.height, 0u);
+    for (size_t k = 0; k < px.size(); ++k) inv[px[k]] = (uint32_t) k;
+    D->pixel_slot = D->track(dev_upload(inv.data(), inv.size(), D->stream));
     D->pixel_list_rank = O.tile_rank; D->pixel_list_count = O.tile_count; D->n_owned_pixels = (uint32_t) px.size();
 }
 
@@ -470,6 +474,7 @@ static void run_wavefront(DeviceScene *D, const lrt_scene_desc &d, const Resolve
                           const uint32_t *pixel_list, float *film, float *sample_out, lrt_render_stats &stats) {
     hipStream_t st = D->stream;
     DRenderParams rp = make_params(d, O, n_lanes);
+    rp.pixel_slot = (sample_out && pixel_list) ? D->pixel_slot : nullptr;
     const bool prb = O.integrator == LRT_INTEGRATOR_PRBVOLPATH;
     PoolGeometry g = pool_geometry(D, n_lanes);
     if (prb && D->use_lds) g.block = 1024;
@@ -519,7 +524,26 @@ void device_render(DeviceScene *D, const lrt_scene_desc &d, const lrt_render_opt
     if (on_device && film_raw) film = film_raw;
     else { if (D->film_floats < film_floats) { HIP_CHECK(hipMalloc((void **) &D->film, film_floats * 4)); D->track(D->film); D->film_floats = film_floats; } film = D->film; }
     HIP_CHECK(hipMemsetAsync(film, 0, film_floats * 4, D->stream));
-    run_wavefront(D, d, O, 0, n_lanes, O.tile_count > 1 ? D->pixel_list : nullptr, film, nullptr, stats);
+    const uint32_t *pixel_list = O.tile_count > 1 ? D->pixel_list : nullptr;
+    if (F.rfilter == LRT_RFILTER_BOX || getenv("LRT_NO_LANE_SPLAT")) run_wavefront(D, d, O, 0, n_lanes, pixel_list, film, nullptr, stats);
+    else {
+        // wide reconstruction filters: per-lane radiance first (16 B / lane, passes of at most 2^28 lanes), then an in-order
+        // splat pass that reduces each pixel's samples inside the wave (k_splat_lanes)
+        const uint64_t pass = std::min<uint64_t>(std::max<uint64_t>(n_lanes, 1), 1ull << 28);
+        ensure_prb_workspace(D, 0, pass);
+        lrt_render_stats total{};
+        for (uint64_t base = 0; base < n_lanes; base += pass) {
+            const uint64_t n = std::min<uint64_t>(pass, n_lanes - base);
+            lrt_render_stats st1{};
+            run_wavefront(D, d, O, base, n, pixel_list, nullptr, reinterpret_cast<float *>(D->L_buf), st1);
+            DRenderParams rp = make_params(d, O, n);
+            k_splat_lanes<<<(uint32_t) ((n + LRT_BLOCK - 1) / LRT_BLOCK), LRT_BLOCK, 0, D->stream>>>(D->sc, rp, D->L_buf, pixel_list, base, n, film);
+            HIP_CHECK(hipGetLastError());
+            total.n_samples += st1.n_samples; total.n_iter += st1.n_iter; total.n_shadow += st1.n_shadow; total.n_launches += st1.n_launches;
+            total.n_records += st1.n_records; total.kernel_ms += st1.kernel_ms; total.total_ms += st1.total_ms;
+        }
+        stats = total;
+    }
     if (image) {
         float *img = image;
         if (!on_device) { if (D->image_floats < image_floats) { HIP_CHECK(hipMalloc((void **) &D->image, image_floats * 4)); D->track(D->image); D->image_floats = image_floats; } img = D->image; }

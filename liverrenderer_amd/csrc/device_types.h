@@ -106,7 +106,8 @@ struct DRenderParams {
     uint32_t seed_value;       // sampler base seed + render seed
     uint32_t tile_rank, tile_count;
     uint32_t tiles_x, tiles_y, profile;   // profile: per-region tile timing into DCounters (developer aid, LRT_DEBUG_LAUNCH)
-    uint64_t n_lanes;          // lanes this rank renders
+    uint64_t n_lanes;          // lanes this launch renders
+    const uint32_t *pixel_slot; // tile-sharded renders: pixel -> index in the rank's pixel list (per-lane output), else null
 };
 
 // Path-state streams (SoA, one float4 / uint2 per path and stream)

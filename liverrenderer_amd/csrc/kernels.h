@@ -116,8 +116,10 @@ DEV float rfilter_eval(const DFilm &F, float x) {
 DEV void finish_path(const DScene &sc, const DRenderParams &rp, float *__restrict__ film, float *__restrict__ sample_out,
                      uint64_t sample_base, uint32_t lane, V3 L, bool valid) {
     if (rp.integrator == LRT_INTEGRATOR_PATH && !valid) L = V3(0.f);                 // path.cpp:342-345
-    if (sample_out) {
-        float4 *o = reinterpret_cast<float4 *>(sample_out) + ((uint64_t) lane - sample_base);
+    if (sample_out) {                               // per-lane output, indexed by the rank-local lane index
+        uint64_t j = lane;
+        if (rp.pixel_slot) { uint32_t pixel = (rp.log2_spp != 0xffffffffu) ? (lane >> rp.log2_spp) : (lane / rp.spp); j = (uint64_t) rp.pixel_slot[pixel] * rp.spp + (lane - pixel * rp.spp); }
+        float4 *o = reinterpret_cast<float4 *>(sample_out) + (j - sample_base);
         *o = make_float4(L.x, L.y, L.z, valid ? 1.f : 0.f);
         return;
     }
@@ -739,6 +741,67 @@ k_build_dist_grid(const float4 *__restrict__ tris, uint32_t n_slots, DDistGrid g
     }
     float d = __builtin_sqrtf(best) * .999f - abs_margin;
     out[c] = d > 0.f ? d : 0.f;
+}
+
+// Film accumulation for reconstruction filters wider than a pixel (Gaussian, tent; imageblock.cpp:174-232,431-500).  The
+// render kernel stores each lane's radiance (16 B / lane); this pass then walks the lanes in order, so the 64 lanes of a
+// wave belong to one or two pixels: the filter footprint of a group of lanes with the same footprint origin is reduced
+// inside the wave (one butterfly per cell and channel) and lane c issues the atomics of cell c.  Compared with splatting
+// where paths happen to retire this divides the float atomics by the group size (up to 64).
+__global__ void __launch_bounds__(LRT_BLOCK)
+k_splat_lanes(DScene sc, DRenderParams rp, const float4 *__restrict__ lane_L, const uint32_t *__restrict__ pixel_list, uint64_t slot_base, uint64_t n,
+              float *__restrict__ film) {
+    const DFilm &F = sc.film;
+    const uint64_t i = (uint64_t) blockIdx.x * LRT_BLOCK + threadIdx.x;
+    const uint32_t me = threadIdx.x & 63u;
+    const bool have = i < n;
+    V3 L(0.f); float alpha = 0.f, relx = 0.f, rely = 0.f; int pix = 0, piy = 0; uint32_t key = 0xffffffffu;
+    if (have) {
+        const uint64_t j = slot_base + i;
+        uint32_t lane;
+        if (pixel_list) { uint32_t pj = (uint32_t) (j / rp.spp); lane = pixel_list[pj] * rp.spp + (uint32_t) (j - (uint64_t) pj * rp.spp); }
+        else lane = (uint32_t) j;
+        const float4 v = lane_L[i];
+        L = V3(v.x, v.y, v.z); alpha = v.w;
+        if (rp.integrator == LRT_INTEGRATOR_PATH && alpha == 0.f) L = V3(0.f);         // path.cpp:342-345
+        PCG32 rng = lane_rng_fresh(rp.seed_value, lane);                                 // the pixel jitter is the stream's first two draws
+        int px, py; lane_to_pixel(sc, rp, lane, &px, &py);
+        float jx = rng.next(), jy = rng.next();
+        float spx = (float) px + jx, spy = (float) py + jy;
+        pix = (int) __builtin_floorf(spx) - F.fn; piy = (int) __builtin_floorf(spy) - F.fn;
+        relx = (float) pix + .5f - spx; rely = (float) piy + .5f - spy;
+        key = (uint32_t) (piy + 0x4000) << 16 | (uint32_t) (pix + 0x4000);
+    }
+    const int count = F.fcount, C = F.channels;
+    unsigned long long todo = __ballot(have);
+    while (todo) {
+        const int leader = __ffsll((long long) todo) - 1;
+        const uint32_t k0 = __shfl(key, leader);
+        const bool mine = have && key == k0;
+        const int gx = __shfl(pix, leader), gy = __shfl(piy, leader);
+        float tr = 0.f, tg = 0.f, tb = 0.f, ta = 0.f, tw = 0.f;         // lane c keeps the totals of footprint cell c
+        for (int ys = 0; ys < count; ++ys) {
+            const float wy = mine ? rfilter_eval(F, rely + (float) ys) : 0.f;
+            for (int xs = 0; xs < count; ++xs) {
+                const float w = mine ? wy * rfilter_eval(F, relx + (float) xs) : 0.f;
+                float r = L.x * w, g = L.y * w, b = L.z * w, a = alpha * w, ww = w;
+                for (int off = 32; off > 0; off >>= 1) {
+                    r += __shfl_xor(r, off); g += __shfl_xor(g, off); b += __shfl_xor(b, off); a += __shfl_xor(a, off); ww += __shfl_xor(ww, off);
+                }
+                if ((int) me == ys * count + xs) { tr = r; tg = g; tb = b; ta = a; tw = ww; }
+            }
+        }
+        if ((int) me < count * count && tw != 0.f) {
+            const int ys = (int) me / count, xs = (int) me - ys * count;
+            const int x = gx - F.crop_offset_x + xs, y = gy - F.crop_offset_y + ys;
+            if (x >= 0 && x < F.width && y >= 0 && y < F.height) {
+                float *p = film + ((size_t) y * F.width + x) * C;
+                atomicAdd(p + 0, tr); atomicAdd(p + 1, tg); atomicAdd(p + 2, tb);
+                if (F.has_alpha) { atomicAdd(p + 3, ta); atomicAdd(p + 4, tw); } else atomicAdd(p + 3, tw);
+            }
+        }
+        todo &= ~__ballot(mine);
+    }
 }
 
 // src/films/hdrfilm.cpp:306-410
