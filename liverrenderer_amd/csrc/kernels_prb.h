@@ -1,6 +1,6 @@
 // Path Replay Backpropagation for homogeneous media: the primal estimator and the
 // hand-derived adjoint of src/python/python/ad/integrators/prbvolpath.py:96-444
-// (driver: src/python/python/ad/integrators/common.py:625-783), as wavefront kernels.
+// (driver: src/python/python/ad/integrators/common.py:625-783), on the persistent render kernel of kernels.h.
 //
 // Differentiated parameters: sigma_t[3], albedo[3] (src/media/homogeneous.cpp:146-151) and the HG
 // asymmetry g (src/phase/hg.cpp:60-62).  With detached sampling the local derivatives are closed forms:
