@@ -238,12 +238,18 @@ LRT_API lrt_status lrt_param_set(lrt_scene *scene, const char *key, const float 
 LRT_API lrt_status lrt_param_get(const lrt_scene *scene, const char *key, float *v, int n);
 
 /* Image files around the path (mi.Bitmap(path) / Bitmap.write, src/core/bitmap.cpp): 8/16-bit PNG and
- * scanline OpenEXR (NONE/ZIPS/ZIP/PIZ) readers, uncompressed float32 EXR writer.  *data is
+ * scanline OpenEXR (NONE/ZIPS/ZIP/PIZ) readers, uncompressed float32 EXR writer, 8-bit sRGB PNG writer.  *data is
  * h * w * channels floats in R,G,B[,A] (or Y[,A]) order, PNG values in [0,1] as stored (no
  * gamma conversion); release it with lrt_image_free.  */
 LRT_API lrt_status lrt_image_read(const char *path, int *width, int *height, int *channels, float **data);
 LRT_API void       lrt_image_free(float *data);
 LRT_API lrt_status lrt_image_write_exr(const char *path, int width, int height, int channels, const float *data);
+/* 8-bit PNG of a LINEAR float image, the export step of LiverRenderer.py:383-385
+ * (Bitmap.convert(RGBA, UInt8, srgb_gamma=True) + write): colour channels through the sRGB transfer
+ * function, alpha linear, clamped to [0,1], rounded to nearest; 1 to 4 channels.  The reference's
+ * blue-noise dithering of 8-bit conversions (src/core/struct.cpp:823-845) is not applied: values agree
+ * with its PNGs to within one code value.                                                    */
+LRT_API lrt_status lrt_image_write_png(const char *path, int width, int height, int channels, const float *data);
 
 #ifdef __cplusplus
 }

@@ -430,6 +430,14 @@ def read_image(path):
         L.lrt_image_free(data)
 
 
+def write_png(path, image):
+    """8-bit sRGB PNG of a linear float image (LiverRenderer.py:383-385: Bitmap.convert(RGBA, UInt8, srgb_gamma=True))."""
+    img = np.ascontiguousarray(image, dtype=np.float32)
+    if img.ndim == 2:
+        img = img[..., None]
+    _lib.check(_lib.lib().lrt_image_write_png(os.fspath(path).encode(), img.shape[1], img.shape[0], img.shape[2], img.ctypes.data))
+
+
 def write_exr(path, image):
     img = np.ascontiguousarray(image, dtype=np.float32)
     if img.ndim == 2:

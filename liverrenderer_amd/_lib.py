@@ -137,7 +137,8 @@ def lib():
     L.lrt_image_free.argtypes = [P(C.c_float)]
     L.lrt_image_free.restype = None
     L.lrt_image_write_exr.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
-    for name in ("lrt_image_read", "lrt_image_write_exr", "lrt_scene_load_xml", "lrt_scene_load_xml_string", "lrt_scene_from_desc", "lrt_render", "lrt_render_stats_get",
+    L.lrt_image_write_png.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    for name in ("lrt_image_read", "lrt_image_write_exr", "lrt_image_write_png", "lrt_scene_load_xml", "lrt_scene_load_xml_string", "lrt_scene_from_desc", "lrt_render", "lrt_render_stats_get",
                  "lrt_film_develop", "lrt_render_samples", "lrt_render_backward", "lrt_trace", "lrt_param_set", "lrt_param_get"):
         getattr(L, name).restype = C.c_int
     _lib = L
@@ -147,7 +148,7 @@ def lib():
 EXPORTED_SYMBOLS = ["lrt_last_error", "lrt_version", "lrt_scene_load_xml", "lrt_scene_load_xml_string", "lrt_scene_from_desc",
                     "lrt_scene_desc_get", "lrt_scene_free", "lrt_render", "lrt_render_stats_get", "lrt_film_develop",
                     "lrt_render_samples", "lrt_render_backward", "lrt_trace", "lrt_param_set", "lrt_param_get",
-                    "lrt_image_read", "lrt_image_free", "lrt_image_write_exr"]
+                    "lrt_image_read", "lrt_image_free", "lrt_image_write_exr", "lrt_image_write_png"]
 
 
 def check(status):

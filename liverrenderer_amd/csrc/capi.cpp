@@ -202,4 +202,12 @@ lrt_status lrt_image_write_exr(const char *path, int width, int height, int chan
     LRT_CATCH
 }
 
+lrt_status lrt_image_write_png(const char *path, int width, int height, int channels, const float *data) {
+    if (!path || !data) return fail(LRT_ERR_INVALID, "lrt_image_write_png: null argument");
+    LRT_TRY
+        write_png(path, width, height, channels, data);
+        return LRT_OK;
+    LRT_CATCH
+}
+
 } // extern "C"

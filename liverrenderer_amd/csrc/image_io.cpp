@@ -401,4 +401,41 @@ void write_exr(const std::string &path, int w, int h, int channels, const float 
     fclose(f);
 }
 
+// 8-bit PNG export of a linear float image, as LiverRenderer.py:383-385 does with
+// Bitmap.convert(RGBA, UInt8, srgb_gamma=True): colour channels through the sRGB OETF, alpha linear, clamp to [0,1],
+// round to nearest.  Filter type 0, one zlib stream, CRCs from zlib.
+void write_png(const std::string &path, int w, int h, int channels, const float *data) {
+    if (channels < 1 || channels > 4) throw std::runtime_error("write_png: 1 to 4 channels expected");
+    const bool has_alpha = channels == 2 || channels == 4;
+    const int n_colour = has_alpha ? channels - 1 : channels;
+    std::vector<uint8_t> raw((size_t) h * ((size_t) w * channels + 1));
+    size_t k = 0;
+    for (int y = 0; y < h; ++y) {
+        raw[k++] = 0;
+        for (int x = 0; x < w; ++x) for (int c = 0; c < channels; ++c) {
+            float v = data[((size_t) y * w + x) * channels + c];
+            if (!(v > 0.f)) v = 0.f;                       // also NaN
+            if (c < n_colour) v = v <= 0.0031308f ? 12.92f * v : 1.055f * std::pow(v, 1.f / 2.4f) - 0.055f;
+            if (v > 1.f) v = 1.f;
+            raw[k++] = (uint8_t) std::lround(v * 255.f);
+        }
+    }
+    uLongf zn = compressBound((uLong) raw.size());
+    std::vector<uint8_t> z(zn);
+    if (compress2(z.data(), &zn, raw.data(), (uLong) raw.size(), 6) != Z_OK) throw std::runtime_error("write_png: deflate failed");
+    FILE *f = fopen(path.c_str(), "wb");
+    if (!f) throw std::runtime_error("cannot open \"" + path + "\" for writing");
+    auto be32 = [](uint32_t v, uint8_t *p) { p[0] = (uint8_t) (v >> 24); p[1] = (uint8_t) (v >> 16); p[2] = (uint8_t) (v >> 8); p[3] = (uint8_t) v; };
+    auto chunk = [&](const char *type, const uint8_t *p, uint32_t n) {
+        uint8_t len[4]; be32(n, len); fwrite(len, 1, 4, f); fwrite(type, 1, 4, f); if (n) fwrite(p, 1, n, f);
+        uLong crc = crc32(0L, (const Bytef *) type, 4); if (n) crc = crc32(crc, p, n);
+        uint8_t c[4]; be32((uint32_t) crc, c); fwrite(c, 1, 4, f);
+    };
+    const uint8_t sig[8] = { 0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a }; fwrite(sig, 1, 8, f);
+    uint8_t ihdr[13]; be32((uint32_t) w, ihdr); be32((uint32_t) h, ihdr + 4);
+    ihdr[8] = 8; ihdr[9] = channels == 1 ? 0 : channels == 2 ? 4 : channels == 3 ? 2 : 6; ihdr[10] = ihdr[11] = ihdr[12] = 0;
+    chunk("IHDR", ihdr, 13); chunk("IDAT", z.data(), (uint32_t) zn); chunk("IEND", nullptr, 0);
+    fclose(f);
+}
+
 } // namespace lrt

@@ -21,5 +21,6 @@ Image read_png(const std::string &path);                  // throws std::runtime
 Image read_exr(const std::string &path);                  // channels in file (alphabetical) order
 Image read_image_rgb(const std::string &path);            // by extension; RGB(A)/Y -> channels as stored
 void  write_exr(const std::string &path, int w, int h, int channels, const float *data);  // RGB / RGBA float32, no compression
+void  write_png(const std::string &path, int w, int h, int channels, const float *data);  // 8-bit, sRGB-encoded colour, linear alpha
 
 } // namespace lrt

@@ -119,6 +119,27 @@ def test_exr_and_png_readers_against_reference_pair(mi):
     assert env.shape == (512, 1024, 4) and np.isfinite(env).all() and (env[..., 3] == 1).all() and 0 < env[..., :3].min() and env.max() <= 1.0
 
 
+def test_png_export_matches_reference_rendition(mi, tmp_path):
+    """Golden pair from the reference tree: exporting its cornell_box.exr the way LiverRenderer.py:383-385 does must give
+    its cornell_box.png within one code value.  (The reference additionally dithers 8-bit conversions with a 256x256
+    blue-noise table, src/core/struct.cpp:823-845, which is not reproduced: about a quarter of the values differ by 1.)"""
+    exr = mi.read_image(os.path.join(ROOT, "tests", "golden", "reference_cornell_box.exr"))
+    ref = mi.read_image(os.path.join(ROOT, "tests", "golden", "reference_cornell_box.png"))
+    p = tmp_path / "c.png"
+    mi.write_png(p, exr)
+    out = mi.read_image(p)
+    assert out.shape == ref.shape
+    d = np.abs(np.round(out * 255) - np.round(ref * 255))
+    assert d.max() <= 1 and (d == 0).mean() > 0.7
+    for ch in (1, 2, 3, 4):                               # round trip of exact code values, all colour types
+        q = np.random.default_rng(ch).integers(0, 256, (5, 9, ch)).astype(np.float32) / 255
+        lin = np.where(q <= 0.04045, q / 12.92, ((q + 0.055) / 1.055) ** 2.4).astype(np.float32)
+        if ch in (2, 4): lin[..., -1] = q[..., -1]
+        mi.write_png(tmp_path / f"r{ch}.png", lin)
+        back = mi.read_image(tmp_path / f"r{ch}.png")
+        assert np.abs(np.round(back * 255) - np.round(q * 255)).max() <= 1
+
+
 def test_exr_writer_roundtrip(mi, tmp_path):
     rng = np.random.default_rng(0)
     for ch in (1, 3, 4):
