@@ -118,6 +118,10 @@ typedef struct {
     const float *data;        /* envmap: h * w * 3 linear RGB floats               */
 } lrt_emitter_desc;
 
+/* samplers: src/samplers/independent.cpp (PCG32 stream per lane), src/samplers/ldsampler.cpp ((0,2)-sequence,
+   TEA-shuffled permutation + per-pixel scramble) */
+enum { LRT_SAMPLER_INDEPENDENT = 0, LRT_SAMPLER_LD = 1 };
+
 typedef struct {
     float   to_world[16];     /* camera-to-world, row-major                        */
     float   fov_x;            /* horizontal field of view, degrees                 */
@@ -157,6 +161,8 @@ typedef struct {
     lrt_integrator_desc integrator;
     uint32_t sample_count;        /* sampler sample_count (default spp)            */
     uint32_t sampler_seed;        /* sampler `seed` property (m_base_seed)         */
+    uint32_t sampler_type;        /* LRT_SAMPLER_*; ld rounds spp up to 4, 16, 64, 256, 1024, ... */
+    uint32_t pad0;
 } lrt_scene_desc;
 
 /* ----------------------------------------------------------- render call */

@@ -65,7 +65,8 @@ class SceneDesc(C.Structure):
                 ("shapes", C.POINTER(ShapeDesc)), ("bsdfs", C.POINTER(BsdfDesc)), ("textures", C.POINTER(TextureDesc)),
                 ("media", C.POINTER(MediumDesc)), ("emitters", C.POINTER(EmitterDesc)),
                 ("sensor", SensorDesc), ("film", FilmDesc), ("integrator", IntegratorDesc),
-                ("sample_count", C.c_uint32), ("sampler_seed", C.c_uint32)]
+                ("sample_count", C.c_uint32), ("sampler_seed", C.c_uint32),
+                ("sampler_type", C.c_uint32), ("pad0", C.c_uint32)]
 
 
 class RenderOpts(C.Structure):

@@ -375,6 +375,11 @@ static ResolvedOpts resolve(const lrt_scene_desc &d, const lrt_render_opts *o) {
     r.rr_depth = (o && o->rr_depth >= 0) ? o->rr_depth : d.integrator.rr_depth;
     r.hide_emitters = (o && o->hide_emitters >= 0) ? (o->hide_emitters != 0) : (d.integrator.hide_emitters != 0);
     r.spp = (o && o->spp) ? o->spp : d.sample_count;
+    if (d.sampler_type == LRT_SAMPLER_LD) {            // integrator.cpp:169-171 + ldsampler.cpp:83-93: a square power of two
+        uint32_t res = 2;
+        while (res * res < r.spp) { ++res; uint32_t p2 = 1; while (p2 < res) p2 <<= 1; res = p2; }
+        r.spp = res * res;
+    }
     r.seed = o ? o->seed : 0;
     r.tile_rank = o ? o->tile_rank : 0; r.tile_count = (o && o->tile_count) ? o->tile_count : 1;
     if (r.tile_rank >= r.tile_count) throw std::runtime_error("tile_rank must be smaller than tile_count");
@@ -415,7 +420,8 @@ static DRenderParams make_params(const lrt_scene_desc &d, const ResolvedOpts &O,
     rp.integrator = O.integrator; rp.max_depth = O.max_depth; rp.rr_depth = O.rr_depth; rp.hide_emitters = O.hide_emitters;
     rp.spp = O.spp; rp.log2_spp = ((O.spp & (O.spp - 1)) == 0) ? (uint32_t) __builtin_ctz(O.spp) : 0xffffffffu;
     rp.profile = (getenv("LRT_DEBUG_LAUNCH") ? 1u : 0u) | (getenv("LRT_EXP") ? (uint32_t) atoi(getenv("LRT_EXP")) : 0u);
-    rp.seed_value = d.sampler_seed + O.seed; rp.tile_rank = O.tile_rank; rp.tile_count = O.tile_count; rp.n_lanes = n_lanes;
+    rp.seed_value = d.sampler_seed + O.seed; rp.base_seed = d.sampler_seed; rp.seed = O.seed;
+    rp.ld_count = d.sampler_type == LRT_SAMPLER_LD ? O.spp : 0u; rp.tile_rank = O.tile_rank; rp.tile_count = O.tile_count; rp.n_lanes = n_lanes;
     return rp;
 }
 

@@ -103,7 +103,9 @@ struct DScene {
 struct DRenderParams {
     int32_t integrator, max_depth, rr_depth, hide_emitters;
     uint32_t spp, log2_spp;    // log2_spp = 0xffffffff when spp is not a power of two
-    uint32_t seed_value;       // sampler base seed + render seed
+    uint32_t seed_value;       // sampler base seed + render seed (independent sampler)
+    uint32_t base_seed, seed;  // the two terms (the ld sampler keys its per-pixel scramble on them separately)
+    uint32_t ld_count, pad1;   // 0: independent sampler; else the ld sampler's sample count (= spp)
     uint32_t tile_rank, tile_count;
     uint32_t tiles_x, tiles_y, profile;   // profile: per-region tile timing into DCounters (developer aid, LRT_DEBUG_LAUNCH)
     uint64_t n_lanes;          // lanes this launch renders

@@ -239,15 +239,72 @@ DEV void tea32(uint32_t v0, uint32_t v1, uint32_t *o0, uint32_t *o1) {
     *o0 = v0; *o1 = v1;
 }
 
+DEV void tea32_rounds2(uint32_t v0, uint32_t v1, uint32_t *o0, uint32_t *o1) {
+    uint32_t sum = 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        sum += 0x9e3779b9u;
+        v0 += ((v1 << 4) + 0xa341316cu) ^ (v1 + sum) ^ ((v1 >> 5) + 0xc8013ea4u);
+        v1 += ((v0 << 4) + 0xad90777du) ^ (v0 + sum) ^ ((v0 >> 5) + 0x7e95761eu);
+    }
+    *o0 = v0; *o1 = v1;
+}
+
+// The lane's sampler as the integrators see it.
+//  * independent (src/samplers/independent.cpp): a PCG32 stream (Dr.Jit's PCG32 = O'Neill's XSH-RR); a masked-out call
+//    draws nothing, so calls simply sit inside the branches.
+//  * low-discrepancy (src/samplers/ldsampler.cpp:112-146, ld_count != 0): a sample is a pure function of (sample index in
+//    the pixel, dimension counter, per-pixel scramble seed): (0,2)-sequence point `permute(index, count, scramble + dim)`
+//    (TEA shuffling network, include/mitsuba/core/random.h:196-214), radical inverse / Sobol' dimension 2
+//    (include/mitsuba/core/qmc.h:189-252) with TEA scrambles.  EVERY call the traced loop body contains bumps the
+//    counter of every lane that is in the loop, whatever the call's mask; skip() stands for the calls a lane's own
+//    control flow does not reach.  Layout: state = dimension counter, inc = scramble_seed | sample_index << 32.
 struct PCG32 {
     uint64_t state, inc;
+    uint32_t ld_count;         // wave-uniform: 0 = independent, else the ld sampler's (rounded) sample count
     DEV uint32_t next_u32() {
         uint64_t old = state;
         state = old * 0x5851f42d4c957f2dULL + inc;
         uint32_t xs = (uint32_t) (((old >> 18) ^ old) >> 27), rot = (uint32_t) (old >> 59);
         return (xs >> rot) | (xs << ((0u - rot) & 31u));
     }
-    DEV float next() { return u2f((next_u32() >> 9) | 0x3f800000u) - 1.f; }
+    DEV uint32_t ld_point() {                        // permuted sample index for the current dimension; advances it
+        const uint32_t scramble_seed = (uint32_t) inc;
+        uint32_t index = (uint32_t) (inc >> 32);
+        const uint32_t perm_seed = scramble_seed + (uint32_t) state;
+        state += 1;
+        for (uint32_t bit = 1; bit < ld_count; bit <<= 1) {
+            uint32_t r0, r1; tea32_rounds2(index | bit, perm_seed, &r0, &r1);
+            if (r0 & bit) index ^= bit;
+        }
+        return index;
+    }
+    DEV static float radical_inverse_2(uint32_t index, uint32_t scramble) {
+        return u2f(((__builtin_bitreverse32(index) ^ scramble) >> 9) | 0x3f800000u) - 1.f;
+    }
+    DEV static float sobol_2(uint32_t index, uint32_t scramble) {
+        for (uint32_t v = 1u << 31; index != 0; index >>= 1, v ^= v >> 1)
+            if (index & 1u) scramble ^= v;
+        return (float) scramble / 4294967296.f;
+    }
+    DEV float next() {
+        if (ld_count) {
+            const uint32_t i = ld_point();
+            uint32_t s0, s1; tea32((uint32_t) inc, 0x48bc48ebu, &s0, &s1);
+            return radical_inverse_2(i, s0);
+        }
+        return u2f((next_u32() >> 9) | 0x3f800000u) - 1.f;
+    }
+    DEV void next2(float &x, float &y) {
+        if (ld_count) {
+            const uint32_t i = ld_point();
+            uint32_t sx, sy; tea32((uint32_t) inc, 0x98bc51abu, &sx, &sy);
+            x = radical_inverse_2(i, sx); y = sobol_2(i, sy);
+            return;
+        }
+        x = u2f((next_u32() >> 9) | 0x3f800000u) - 1.f; y = u2f((next_u32() >> 9) | 0x3f800000u) - 1.f;
+    }
+    DEV void skip(uint32_t n) { if (ld_count) state += n; }
     DEV void seed(uint64_t initstate, uint64_t initseq) {
         state = 0; inc = (initseq << 1) | 1u; next_u32(); state += initstate; next_u32();
     }

@@ -35,13 +35,26 @@ DEV void store_state(const DPathStreams &q, uint32_t i, const PathState &s) {
     q.rng[i] = make_uint2((uint32_t) s.rng_state, (uint32_t) (s.rng_state >> 32));
 }
 
-DEV PCG32 lane_rng_fresh(uint32_t seed_value, uint32_t lane) {
-    uint32_t v0, v1; tea32(seed_value, lane, &v0, &v1);
-    PCG32 r; r.seed(v0, v1); return r;
-}
-DEV uint64_t lane_rng_inc(uint32_t seed_value, uint32_t lane) {
-    uint32_t v0, v1; tea32(seed_value, lane, &v0, &v1);
+// Sampler::seed in the JIT branch of SamplingIntegrator::render (integrator.cpp:308-311): independent: TEA4(base + seed,
+// lane) seeds the PCG32 stream (sampler.cpp:129-148); ld: the sequence is the lane's pixel, scramble seed =
+// TEA4(base, spp * pixel + seed).first (sampler.cpp:97-107), sample index = lane % spp (:109-117).
+DEV uint64_t lane_rng_inc(const DRenderParams &rp, uint32_t lane) {
+    if (rp.ld_count) {
+        const uint32_t pixel = (rp.log2_spp != 0xffffffffu) ? (lane >> rp.log2_spp) : (lane / rp.spp);
+        uint32_t v0, v1; tea32(rp.base_seed, rp.spp * pixel + rp.seed, &v0, &v1);
+        return (uint64_t) v0 | ((uint64_t) (lane - pixel * rp.spp) << 32);
+    }
+    uint32_t v0, v1; tea32(rp.seed_value, lane, &v0, &v1);
     return ((uint64_t) v1 << 1) | 1u;
+}
+DEV PCG32 lane_rng_fresh(const DRenderParams &rp, uint32_t lane) {
+    PCG32 r; r.ld_count = rp.ld_count;
+    if (rp.ld_count) { r.state = 0; r.inc = lane_rng_inc(rp, lane); return r; }
+    uint32_t v0, v1; tea32(rp.seed_value, lane, &v0, &v1);
+    r.seed(v0, v1); return r;
+}
+DEV PCG32 lane_rng_resume(const DRenderParams &rp, uint32_t lane, uint64_t state) {
+    PCG32 r; r.ld_count = rp.ld_count; r.state = state; r.inc = lane_rng_inc(rp, lane); return r;
 }
 
 // lane -> pixel (src/render/integrator.cpp:321-338); tile-sharded renders go
@@ -77,9 +90,9 @@ DEV PathState generate_camera_path(const DScene &sc, const DRenderParams &rp, co
     uint32_t lane;
     if (pixel_list) { uint32_t pj = (uint32_t) (j / rp.spp); lane = pixel_list[pj] * rp.spp + (uint32_t) (j - (uint64_t) pj * rp.spp); }
     else lane = (uint32_t) j;
-    PCG32 rng = lane_rng_fresh(rp.seed_value, lane);
+    PCG32 rng = lane_rng_fresh(rp, lane);
     int px, py; lane_to_pixel(sc, rp, lane, &px, &py);
-    float jx = rng.next(), jy = rng.next();
+    float jx, jy; rng.next2(jx, jy);
     float spx = (float) px + jx, spy = (float) py + jy;
     Ray ray = camera_ray(sc, fma_(spx, sc.film.scale_x, sc.film.offset_x), fma_(spy, sc.film.scale_y, sc.film.offset_y));
     PathState s;
@@ -138,8 +151,8 @@ DEV void finish_path(const DScene &sc, const DRenderParams &rp, float *__restric
         if (F.has_alpha) { atomicAdd(p + 3, alpha); atomicAdd(p + 4, 1.f); } else atomicAdd(p + 3, 1.f);
         return;
     }
-    PCG32 rng = lane_rng_fresh(rp.seed_value, lane);                                 // the pixel jitter is the stream's first two draws
-    float jx = rng.next(), jy = rng.next();
+    PCG32 rng = lane_rng_fresh(rp, lane);                                 // the pixel jitter is the stream's first two draws
+    float jx, jy; rng.next2(jx, jy);
     float spx = (float) px + jx, spy = (float) py + jy;
     int n = F.fn, count = F.fcount;
     int pix = (int) __builtin_floorf(spx) - n, piy = (int) __builtin_floorf(spy) - n;
@@ -208,7 +221,7 @@ template <typename TR>
 DEV V3 volpath_sample_emitter(const DScene &sc, PCG32 &rng, V3 ref_p, V3 ref_n, bool ref_is_surface, uint32_t ref_shape, V3 ref_geo_n,
                               int medium, uint32_t channel, DirSample *ds_out, const TR &tr, uint32_t &n_shadow) {
     V3 transmittance(1.f);
-    float sx = rng.next(), sy = rng.next();
+    float sx, sy; rng.next2(sx, sy);
     DirSample ds; V3 emitter_val = sample_emitter_direction(sc, ref_p, sx, sy, &ds);
     *ds_out = ds;
     if (ds.pdf == 0.f) return V3(0.f);
@@ -221,8 +234,9 @@ DEV V3 volpath_sample_emitter(const DScene &sc, PCG32 &rng, V3 ref_p, V3 ref_n, 
     while (active) {
         float remaining_dist = max_dist - total_dist;
         ray.maxt = remaining_dist;
-        if (!(remaining_dist > 0.f)) break;
+        if (!(remaining_dist > 0.f)) { rng.skip(1); break; }           // the body still runs (masked) in this last trip
         bool escaped_medium = false, active_medium = medium >= 0, active_surface = !active_medium;
+        if (!active_medium) rng.skip(1);                                // volpath.cpp:479
         if (active_medium) {
             const DMedium M = sc.media[medium];
             MI mei = medium_sample_interaction(M, ray, rng.next(), channel);
@@ -304,6 +318,7 @@ DEV bool volpath_iteration(const DScene &sc, const DRenderParams &rp, PathState 
     bool act_medium_scatter = false, escaped_medium = false;
     MI mei; mei.t = kInf;
     SI si; si.valid = false; si.t = kInf;
+    if (!active_medium) rng.skip(2);                                    // volpath.cpp:220,239
     if (active_medium) {
         const DMedium M = sc.media[medium];
         mei = medium_sample_interaction(M, ray, rng.next(), channel);
@@ -323,6 +338,7 @@ DEV bool volpath_iteration(const DScene &sc, const DRenderParams &rp, PathState 
         }
         escaped_medium = !mei.valid();
         active_medium = mei.valid();
+        if (!active_medium) rng.skip(1);              // volpath.cpp:239
         if (active_medium) {
             (void) rng.next();                        // null/real collision draw (sigma_n = 0: always real)
             act_medium_scatter = true;
@@ -332,6 +348,7 @@ DEV bool volpath_iteration(const DScene &sc, const DRenderParams &rp, PathState 
     }
     active = active && depth < max_depth;
     act_medium_scatter = act_medium_scatter && active;
+    if (!act_medium_scatter) rng.skip(3);                               // volpath.cpp:407 (NEE), 288, 289
     if (act_medium_scatter) {
         const DMedium M = sc.media[medium];
         if (M.has_spectral_extinction) throughput = throughput * (mei.sigma_s / mean3(mei.sigma_t / mei.combined));
@@ -339,6 +356,7 @@ DEV bool volpath_iteration(const DScene &sc, const DRenderParams &rp, PathState 
         bool sample_emitters = M.sample_emitters != 0;
         valid_ray = true;
         specular_chain = !sample_emitters;
+        if (!sample_emitters) rng.skip(1);
         if (sample_emitters) {
             // Exact early rejection (sc.nee_fast_reject: one infinite emitter, no null BSDF in the scene).  The emitter
             // sample lies at distance 2*max(r_bsphere, |p - c|) whatever its direction (envmap.cpp:431-433,
@@ -350,7 +368,8 @@ DEV bool volpath_iteration(const DScene &sc, const DRenderParams &rp, PathState 
             bool rejected = false;
             if (sc.nee_fast_reject) {
                 PCG32 saved = rng;
-                float sx = rng.next(), sy = rng.next(), u3 = rng.next();
+                float sx, sy; rng.next2(sx, sy);                        // the emitter sample, then the march's single draw
+                float u3 = rng.next();
                 const float lo = 9.5367431640625e-7f, hi = 1.f - 9.5367431640625e-7f;
                 bool interior = sc.env.type == LRT_EMITTER_CONSTANT || (sx > lo && sx < hi && sy > lo && sy < hi);
                 float sampled_t = 0.f + (-m_log(1.f - u3) / idx3(V3(M.sigma_t[0], M.sigma_t[1], M.sigma_t[2]), channel));
@@ -368,7 +387,7 @@ DEV bool volpath_iteration(const DScene &sc, const DRenderParams &rp, PathState 
             }
         }
         (void) rng.next();
-        float s2x = rng.next(), s2y = rng.next();
+        float s2x, s2y; rng.next2(s2x, s2y);
         V3 wo; float phase_pdf; phase_sample(M, mei.wi, s2x, s2y, &wo, &phase_pdf);
         if (phase_pdf > 0.f) {
             ray = spawn_ray(mei.p, V3(0.f), wo);
@@ -405,11 +424,13 @@ DEV bool volpath_iteration(const DScene &sc, const DRenderParams &rp, PathState 
         }
     }
     active_surface = active_surface && si.valid;
+    if (!active_surface) rng.skip(3);                                   // volpath.cpp:407 (NEE), 366, 367
     if (active_surface) {
         const DShape sd = sc.shapes[si.shape];
         int b = sd.bsdf;
         int flags = sc.bsdfs[b].flags;
         bool active_e = (flags & F_SMOOTH) && (depth + 1 < max_depth);
+        if (!active_e) rng.skip(1);
         if (active_e) {
             DirSample ds;
             V3 emitted = volpath_sample_emitter(sc, rng, si.p, si.n, true, si.shape, si.n, medium, channel, &ds, tr, n_shadow);
@@ -419,7 +440,7 @@ DEV bool volpath_iteration(const DScene &sc, const DRenderParams &rp, PathState 
             V3 c = throughput * bsdf_val * mis_weight(ds.pdf, ds.delta ? 0.f : bpdf) * emitted;
             result = result + c;
         }
-        float s1 = rng.next(), s2x = rng.next(), s2y = rng.next();
+        float s1 = rng.next(), s2x, s2y; rng.next2(s2x, s2y);
         const BSDFSample bs = bsdf_sample(sc, b, si, s1, s2x, s2y);
         throughput = throughput * bs.weight;
         eta *= bs.eta;
@@ -511,8 +532,10 @@ DEV bool path_iteration(const DScene &sc, const DRenderParams &rp, PathState &s,
     bool active_em = (sc.bsdfs[b].flags & F_SMOOTH) != 0;
     DirSample ds; ds.pdf = 0.f; ds.delta = false; ds.d = V3(0.f);
     V3 em_weight(0.f), wo(0.f);
+    // path.cpp:246-248: ls.sampler->next_2d() carries no mask and sits in an `if (dr::any_or<true>(active_em))`, which a
+    // symbolic loop always traces: every lane in the loop consumes the two numbers, smooth BSDF or not
+    float sx, sy; rng.next2(sx, sy);
     if (active_em) {
-        float sx = rng.next(), sy = rng.next();
         em_weight = sample_emitter_direction(sc, si.p, sx, sy, &ds);
         if (ds.pdf != 0.f) {                                       // scene.cpp:361-365 test_visibility
             Ray sr = spawn_ray_to(si.p, si.n, ds.p);
@@ -523,7 +546,7 @@ DEV bool path_iteration(const DScene &sc, const DRenderParams &rp, PathState &s,
         active_em = ds.pdf != 0.f;
         wo = si.sh.to_local(ds.d);
     }
-    float s1 = rng.next(), s2x = rng.next(), s2y = rng.next();
+    float s1 = rng.next(), s2x, s2y; rng.next2(s2x, s2y);
     V3 bsdf_val = bsdf_eval(sc, b, si, wo);
     float bpdf = bsdf_pdf(sc, b, si, wo);
     const BSDFSample bs = bsdf_sample(sc, b, si, s1, s2x, s2y);
@@ -659,7 +682,7 @@ k_render(DScene sc, DRenderParams rp, DLdsInfo li, DPathStreams q0, DPathStreams
             } else
 #endif
             if (had_path) {
-                PCG32 rng; rng.state = s.rng_state; rng.inc = lane_rng_inc(rp.seed_value, s.lane);
+                PCG32 rng = lane_rng_resume(rp, s.lane, s.rng_state);
                 if (INTEGRATOR == LRT_INTEGRATOR_PATH) alive = LDS_BVH ? path_iteration(sc, rp, s, rng, tr_lds, n_shadow) : path_iteration(sc, rp, s, rng, tr_glb, n_shadow);
                 else alive = LDS_BVH ? volpath_iteration(sc, rp, s, rng, tr_lds, n_shadow, n_extra) : volpath_iteration(sc, rp, s, rng, tr_glb, n_shadow, n_extra);
                 s.rng_state = rng.state;
@@ -672,7 +695,7 @@ k_render(DScene sc, DRenderParams rp, DLdsInfo li, DPathStreams q0, DPathStreams
                 if ((rp.profile >> (8 + kind)) & 1u) {
                     PathState s2 = s_saved; bool alive2 = false; uint32_t d0 = 0, d1 = 0;
                     if (had_path) {
-                        PCG32 rng; rng.state = s2.rng_state; rng.inc = lane_rng_inc(rp.seed_value, s2.lane);
+                        PCG32 rng = lane_rng_resume(rp, s2.lane, s2.rng_state);
                         if (INTEGRATOR == LRT_INTEGRATOR_PATH) alive2 = LDS_BVH ? path_iteration(sc, rp, s2, rng, tr_lds, d0) : path_iteration(sc, rp, s2, rng, tr_glb, d0);
                         else alive2 = LDS_BVH ? volpath_iteration(sc, rp, s2, rng, tr_lds, d0, d1) : volpath_iteration(sc, rp, s2, rng, tr_glb, d0, d1);
                     }
@@ -764,9 +787,9 @@ k_splat_lanes(DScene sc, DRenderParams rp, const float4 *__restrict__ lane_L, co
         const float4 v = lane_L[i];
         L = V3(v.x, v.y, v.z); alpha = v.w;
         if (rp.integrator == LRT_INTEGRATOR_PATH && alpha == 0.f) L = V3(0.f);         // path.cpp:342-345
-        PCG32 rng = lane_rng_fresh(rp.seed_value, lane);                                 // the pixel jitter is the stream's first two draws
+        PCG32 rng = lane_rng_fresh(rp, lane);                                 // the pixel jitter is the stream's first two draws
         int px, py; lane_to_pixel(sc, rp, lane, &px, &py);
-        float jx = rng.next(), jy = rng.next();
+        float jx, jy; rng.next2(jx, jy);
         float spx = (float) px + jx, spy = (float) py + jy;
         pix = (int) __builtin_floorf(spx) - F.fn; piy = (int) __builtin_floorf(spy) - F.fn;
         relx = (float) pix + .5f - spx; rely = (float) piy + .5f - spy;

@@ -26,7 +26,7 @@ DEV float hg_dlog_dg(float g, float c) {
 template <typename TR>
 DEV V3 prb_sample_emitter(const DScene &sc, PCG32 &rng, V3 ref_p, V3 ref_n, bool ref_is_surface, uint32_t ref_shape, V3 ref_geo_n,
                           int medium, uint32_t channel, DirSample *ds_out, const TR &tr, uint32_t &n_shadow, V3 *seg_sum) {
-    float sx = rng.next(), sy = rng.next();
+    float sx, sy; rng.next2(sx, sy);
     DirSample ds; V3 emitter_val = sample_emitter_direction(sc, ref_p, sx, sy, &ds);
     *ds_out = ds;
     bool active = ds.pdf != 0.f;
@@ -47,6 +47,7 @@ DEV V3 prb_sample_emitter(const DScene &sc, PCG32 &rng, V3 ref_p, V3 ref_n, bool
         bool active_medium = active && medium >= 0, active_surface = active && !active_medium;
         V3 tr_multiplier(1.f);
         float seg_t = 0.f, scale_t = 0.f; bool escaped_medium = false;
+        if (!active_medium) rng.skip(1);             // prbvolpath.py:396: the call runs for every lane in the march
         if (active_medium) {
             (void) rng.next();
             const DMedium M = sc.media[medium];
@@ -104,6 +105,7 @@ DEV bool prb_iteration(const DScene &sc, const DRenderParams &rp, PathState &s, 
     SI si; si.valid = false; si.t = kInf;
     V3 weight(1.f);
     float seg_t = 0.f;
+    if (!active_medium) rng.skip(1);                  // prbvolpath.py:158
     if (active_medium) {
         const DMedium M = sc.media[medium];
         mei = medium_sample_interaction(M, ray, rng.next(), channel);
@@ -169,6 +171,7 @@ DEV bool prb_iteration(const DScene &sc, const DRenderParams &rp, PathState &s, 
     bool sample_emitters = act_medium_scatter ? (sc.media[medium].sample_emitters != 0) : false;
     if (act_medium_scatter) specular_chain = !sample_emitters;
     bool active_e_medium = act_medium_scatter && sample_emitters;
+    if (!(active_e_surface || active_e_medium)) rng.skip(1);           // prbvolpath.py:365
     if (active_e_surface || active_e_medium) {
         DirSample ds; V3 seg_sum;
         V3 rp_ = active_e_medium ? mei.p : si.p, rn = active_e_medium ? V3(0.f) : si.n;
@@ -185,11 +188,12 @@ DEV bool prb_iteration(const DScene &sc, const DRenderParams &rp, PathState &s, 
         }
     }
     // ---- phase function sampling (prbvolpath.py:299-317)
+    if (!act_medium_scatter) rng.skip(2);             // prbvolpath.py:294-295
     if (act_medium_scatter) {
         valid_ray = true;
         const DMedium M = sc.media[medium];
         (void) rng.next();
-        float s2x = rng.next(), s2y = rng.next();
+        float s2x, s2y; rng.next2(s2x, s2y);
         V3 wo; float phase_pdf; phase_sample(M, mei.wi, s2x, s2y, &wo, &phase_pdf);
         act_medium_scatter = phase_pdf > 0.f;
         if (act_medium_scatter) {
@@ -204,9 +208,10 @@ DEV bool prb_iteration(const DScene &sc, const DRenderParams &rp, PathState &s, 
         }
     }
     // ---- BSDF sampling (prbvolpath.py:321-349)
+    if (!active_surface) rng.skip(2);                 // prbvolpath.py:317-318
     if (active_surface) {
         const DShape sd = sc.shapes[si.shape];
-        float s1 = rng.next(), s2x = rng.next(), s2y = rng.next();
+        float s1 = rng.next(), s2x, s2y; rng.next2(s2x, s2y);
         const BSDFSample bs = bsdf_sample(sc, b, si, s1, s2x, s2y);
         active_surface = bs.pdf > 0.f;
         if (active_surface) {
@@ -227,9 +232,9 @@ DEV bool prb_iteration(const DScene &sc, const DRenderParams &rp, PathState &s, 
 
 // Filter footprint helpers shared by the weight-film and delta_L kernels (imageblock.cpp:431-500)
 DEV void lane_sample_pos(const DScene &sc, const DRenderParams &rp, uint32_t lane, float *spx, float *spy, int *px, int *py) {
-    PCG32 rng = lane_rng_fresh(rp.seed_value, lane);
+    PCG32 rng = lane_rng_fresh(rp, lane);
     lane_to_pixel(sc, rp, lane, px, py);
-    float jx = rng.next(), jy = rng.next();
+    float jx, jy; rng.next2(jx, jy);
     *spx = (float) *px + jx; *spy = (float) *py + jy;
 }
 
@@ -365,7 +370,7 @@ k_render_prb(DScene sc, DRenderParams rp, DLdsInfo li, DPathStreams q0, DPathStr
             }
             PrbGrads G; G.sigma_t[0] = G.sigma_t[1] = G.sigma_t[2] = G.albedo[0] = G.albedo[1] = G.albedo[2] = G.g = 0.f;
             if (had_path) {
-                PCG32 rng; rng.state = s.rng_state; rng.inc = lane_rng_inc(rp.seed_value, s.lane);
+                PCG32 rng = lane_rng_resume(rp, s.lane, s.rng_state);
                 alive = LDS_BVH ? prb_iteration<ADJOINT>(sc, rp, s, rng, tr_lds, n_shadow, V3(dl.x, dl.y, dl.z), G)
                                 : prb_iteration<ADJOINT>(sc, rp, s, rng, tr_glb, n_shadow, V3(dl.x, dl.y, dl.z), G);
                 s.rng_state = rng.state;

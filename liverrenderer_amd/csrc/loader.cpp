@@ -3,7 +3,7 @@
 // Replaces, for the plugins the liver scenes and mi.cornell_box() use, the
 // reference's src/core/parser.cpp + Properties + PluginManager instantiation.
 // Supported plugins: integrator {path, volpath, prbvolpath}; sensor perspective;
-// sampler {independent, ldsampler(->independent)}; film hdrfilm; rfilter {box,
+// sampler {independent, ldsampler}; film hdrfilm; rfilter {box,
 // gaussian, tent}; bsdf {diffuse, dielectric, bumpmap, null}; texture {bitmap,
 // checkerboard}; medium {homogeneous, liver, parenchyma, glissonCapsule} (the
 // bio media are read as the base-class homogeneous medium their 4-argument
@@ -496,10 +496,16 @@ struct Loader {
         } else { F.crop_width = F.width; F.crop_height = F.height; }
         if (F.crop_width <= 0 || F.crop_height <= 0 || F.crop_offset_x < 0 || F.crop_offset_y < 0 || F.crop_offset_x + F.crop_width > F.width || F.crop_offset_y + F.crop_height > F.height)
             fail("Invalid crop window specification!");
-        S.desc.sample_count = 4; S.desc.sampler_seed = 0;
+        S.desc.sample_count = 4; S.desc.sampler_seed = 0; S.desc.sampler_type = LRT_SAMPLER_INDEPENDENT;
         if (sampler) {
             if (sampler->type != "independent" && sampler->type != "ldsampler") fail("unsupported sampler type \"" + sampler->type + "\"");
             S.desc.sample_count = (uint32_t) get_int(*sampler, "sample_count", 4); S.desc.sampler_seed = (uint32_t) get_int(*sampler, "seed", 0);
+            if (sampler->type == "ldsampler") {            // ldsampler.cpp:83-93: sample_count is rounded up to a square power of two
+                S.desc.sampler_type = LRT_SAMPLER_LD;
+                uint32_t res = 2;
+                while (res * res < S.desc.sample_count) { ++res; uint32_t p2 = 1; while (p2 < res) p2 <<= 1; res = p2; }
+                S.desc.sample_count = res * res;
+            }
         }
         // src/render/sensor.cpp:123-132,142-196 (parse_fov)
         C.near_clip = get_float(*o, "near_clip", 1e-2f); C.far_clip = get_float(*o, "far_clip", 1e4f);

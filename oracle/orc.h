@@ -68,6 +68,9 @@ int orc_trace(orc_scene *s, const lrt_rays_soa *rays, const lrt_hits_soa *hits,
 
 /* Unit-level entry points for pinning tests. */
 void  orc_tea32(uint32_t v0, uint32_t v1, int rounds, uint32_t *out0, uint32_t *out1);
+void  orc_ld_sample(uint32_t sample_count, uint32_t scramble_seed, uint32_t sample_index, uint32_t dim, int two_d, float *out);
+uint32_t orc_ld_round_sample_count(uint32_t spp);
+uint32_t orc_permute(uint32_t i, uint32_t n, uint32_t seed);
 float orc_tea_float32(uint32_t v0, uint32_t v1, int rounds);
 double orc_tea_float64(uint32_t v0, uint32_t v1, int rounds);
 void  orc_pcg32_u32(uint64_t initstate, uint64_t initseq, uint32_t n, uint32_t *out);

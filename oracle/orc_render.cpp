@@ -45,6 +45,71 @@ static inline PCG32 lane_rng(uint32_t base_seed, uint32_t seed, uint32_t lane) {
     PCG32 r; r.seed(v0, v1); return r;
 }
 
+/* src/samplers/ldsampler.cpp:75-160 (+ include/mitsuba/core/random.h:196-214 permute,
+   include/mitsuba/core/qmc.h:189-252 radical_inverse_2 / sobol_2, src/render/sampler.cpp:97-117).
+   A sample is a pure function of (sample index within the pixel, dimension counter, per-pixel scramble seed). */
+static inline uint32_t permute_tea(uint32_t index, uint32_t size, uint32_t seed) {     /* random.h:196-214 permute(), rounds = 2 */
+    for (uint32_t bit = 1; bit < size; bit <<= 1) {                                     /* size is a power of two */
+        uint32_t r0, r1; tea32(index | bit, seed, 2, &r0, &r1);
+        if (r0 & bit) index ^= bit;
+    }
+    return index;
+}
+static inline float radical_inverse_2(uint32_t index, uint32_t scramble) {
+    index = (index << 16) | (index >> 16);
+    index = ((index & 0x00ff00ffu) << 8) | ((index & 0xff00ff00u) >> 8);
+    index = ((index & 0x0f0f0f0fu) << 4) | ((index & 0xf0f0f0f0u) >> 4);
+    index = ((index & 0x33333333u) << 2) | ((index & 0xccccccccu) >> 2);
+    index = ((index & 0x55555555u) << 1) | ((index & 0xaaaaaaaau) >> 1);
+    return u2f(((index ^ scramble) >> 9) | 0x3f800000u) - 1.f;
+}
+static inline float sobol_2(uint32_t index, uint32_t scramble) {
+    for (uint32_t v = 1u << 31; index != 0; index >>= 1, v ^= v >> 1)
+        if (index & 1u) scramble ^= v;
+    return (float) scramble / 4294967296.f;             /* Float(scramble) / Float(1ULL << 32) */
+}
+/* LowDiscrepancySampler::set_sample_count (ldsampler.cpp:83-93): round up to a square power of two */
+static inline uint32_t ld_round_sample_count(uint32_t spp) {
+    uint32_t res = 2;
+    while (res * res < spp) { ++res; uint32_t p = 1; while (p < res) p <<= 1; res = p; }
+    return res * res;
+}
+
+/* The integrators' view of a sampler.  Independent: the lane's PCG32 stream, a masked-out call draws nothing.
+   Low-discrepancy: EVERY call the loop body executes bumps the dimension counter of every lane that is in the loop,
+   whatever the call's mask (m_dimension_index++ is unmasked and the body of a symbolic loop is traced once, with all
+   its `if (dr::any_or<true>(...))` blocks); skip() stands for the calls a lane's own control flow does not reach. */
+struct Sampler {
+    int type = LRT_SAMPLER_INDEPENDENT;
+    PCG32 rng;
+    uint32_t dim = 0, scramble_seed = 0, sample_index = 0, sample_count = 1;
+    float next1() {
+        if (type != LRT_SAMPLER_LD) return rng.next();
+        uint32_t perm_seed = scramble_seed + dim++;
+        uint32_t i = permute_tea(sample_index, sample_count, perm_seed);
+        uint32_t s0, s1; tea32(scramble_seed, 0x48bc48ebu, 4, &s0, &s1);
+        return radical_inverse_2(i, s0);
+    }
+    void next2(float *x, float *y) {
+        if (type != LRT_SAMPLER_LD) { *x = rng.next(); *y = rng.next(); return; }
+        uint32_t perm_seed = scramble_seed + dim++;
+        uint32_t i = permute_tea(sample_index, sample_count, perm_seed);
+        uint32_t sx, sy; tea32(scramble_seed, 0x98bc51abu, 4, &sx, &sy);
+        *x = radical_inverse_2(i, sx); *y = sobol_2(i, sy);
+    }
+    void skip(uint32_t n) { if (type == LRT_SAMPLER_LD) dim += n; }
+};
+/* Sampler::seed in the JIT branch of SamplingIntegrator::render (integrator.cpp:308-311, sampler.cpp:97-117):
+   sequence = the lane's pixel (samples_per_wavefront = spp), sample index = lane % spp */
+static inline Sampler lane_sampler(int type, uint32_t base_seed, uint32_t seed, uint32_t lane, uint32_t spp) {
+    Sampler s; s.type = type;
+    if (type == LRT_SAMPLER_LD) {
+        uint32_t v0, v1; tea32(base_seed, spp * (lane / spp) + seed, 4, &v0, &v1);
+        s.scramble_seed = v0; s.sample_index = lane % spp; s.sample_count = spp; s.dim = 0;
+    } else s.rng = lane_rng(base_seed, seed, lane);
+    return s;
+}
+
 /* ---------------------------------------------------------------- sensor */
 /* src/sensors/perspective.cpp:239-279 (differentials unused: volpath.cpp:107, no ray-differential consumers) */
 static Ray sample_ray(const Scene &S, float px, float py) {
@@ -446,10 +511,12 @@ static float phase_eval(const lrt_medium_desc &M, V3 wi, V3 wo) {
 
 /* ------------------------------------------------------------ integrators */
 struct Ctx {
-    const Scene &S; PCG32 rng; int max_depth, rr_depth; bool hide_emitters;
+    const Scene &S; Sampler smp; int max_depth, rr_depth; bool hide_emitters;
     uint64_t n_iter = 0, n_shadow = 0, n_shadow_needed = 0;
     Ctx(const Scene &s) : S(s) {}
-    float next() { return rng.next(); }
+    float next() { return smp.next1(); }
+    void next2(float *x, float *y) { smp.next2(x, y); }
+    void skip(uint32_t n) { smp.skip(n); }
 };
 
 static inline int target_medium(const lrt_shape_desc &sd, V3 d, V3 n) {   /* interaction.h:330-344 */
@@ -461,7 +528,7 @@ static inline bool is_medium_transition(const lrt_shape_desc &sd) { return sd.in
 static V3 volpath_sample_emitter(Ctx &C, V3 ref_p, V3 ref_n, const SI *ref_si, int medium, uint32_t channel, DirSample *ds_out) {
     const Scene &S = C.S;
     V3 transmittance(1.f);
-    float sx = C.next(), sy = C.next();
+    float sx, sy; C.next2(&sx, &sy);
     DirSample ds; V3 emitter_val = sample_emitter_direction(S, ref_p, sx, sy, &ds);
     *ds_out = ds;
     if (ds.pdf == 0.f) return V3(0.f);
@@ -475,8 +542,9 @@ static V3 volpath_sample_emitter(Ctx &C, V3 ref_p, V3 ref_n, const SI *ref_si, i
     while (active) {
         float remaining_dist = max_dist - total_dist;
         ray.maxt = remaining_dist;
-        if (!(remaining_dist > 0.f)) break;
+        if (!(remaining_dist > 0.f)) { C.skip(1); break; }          /* the body still runs (masked) in this last trip */
         bool escaped_medium = false, active_medium = medium >= 0, active_surface = !active_medium;
+        if (!active_medium) C.skip(1);                                /* volpath.cpp:479 */
         if (active_medium) {
             const lrt_medium_desc &M = S.media[medium];
             MI mei = medium_sample_interaction(S, medium, ray, C.next(), channel);
@@ -564,6 +632,7 @@ static void volpath_sample(Ctx &C, Ray ray, int medium, V3 *out, bool *out_valid
         bool active_medium = medium >= 0, active_surface = !active_medium;
         bool act_medium_scatter = false, escaped_medium = false;
         MI mei; mei.t = kInf;
+        if (!active_medium) C.skip(2);                                /* volpath.cpp:220,239 */
         if (active_medium) {
             const lrt_medium_desc &M = S.media[medium];
             mei = medium_sample_interaction(S, medium, ray, C.next(), channel);
@@ -580,6 +649,7 @@ static void volpath_sample(Ctx &C, Ray ray, int medium, V3 *out, bool *out_valid
             }
             escaped_medium = !mei.valid();
             active_medium = mei.valid();
+            if (!active_medium) C.skip(1);                            /* volpath.cpp:239 */
             if (active_medium) {
                 float null_scatter_prob = mean3(mei.sigma_n / mei.combined);
                 bool null_scatter = C.next() < null_scatter_prob;
@@ -592,6 +662,7 @@ static void volpath_sample(Ctx &C, Ray ray, int medium, V3 *out, bool *out_valid
         }
         active = active && depth < max_depth;
         act_medium_scatter = act_medium_scatter && active;
+        if (!act_medium_scatter) C.skip(3);                           /* volpath.cpp:407 (NEE), 288, 289 */
         if (act_medium_scatter) {
             const lrt_medium_desc &M = S.media[medium];
             if (M.has_spectral_extinction) throughput *= mei.sigma_s / mean3(mei.sigma_t / mei.combined);
@@ -599,6 +670,7 @@ static void volpath_sample(Ctx &C, Ray ray, int medium, V3 *out, bool *out_valid
             bool sample_emitters = M.sample_emitters;
             valid_ray = true;
             specular_chain = !sample_emitters;
+            if (!sample_emitters) C.skip(1);
             if (sample_emitters) {
                 DirSample ds;
                 V3 emitted = volpath_sample_emitter(C, mei.p, V3(0.f), nullptr, medium, channel, &ds);
@@ -606,7 +678,7 @@ static void volpath_sample(Ctx &C, Ray ray, int medium, V3 *out, bool *out_valid
                 result += throughput * phase_val * emitted * mis_weight(ds.pdf, ds.delta ? 0.f : phase_val);
             }
             float s1 = C.next(); (void) s1;
-            float s2x = C.next(), s2y = C.next();
+            float s2x, s2y; C.next2(&s2x, &s2y);
             V3 wo; float phase_pdf; phase_sample(M, mei.wi, s2x, s2y, &wo, &phase_pdf);
             act_medium_scatter = phase_pdf > 0.f;
             if (act_medium_scatter) {
@@ -648,11 +720,13 @@ static void volpath_sample(Ctx &C, Ray ray, int medium, V3 *out, bool *out_valid
             }
         }
         active_surface = active_surface && si.valid;
+        if (!active_surface) C.skip(3);                               /* volpath.cpp:407 (NEE), 366, 367 */
         if (active_surface) {
             const lrt_shape_desc &sd = S.shapes[si.shape];
             int b = sd.bsdf;
             int flags = bsdf_flags(S, b);
             bool active_e = (flags & F_SMOOTH) && (depth + 1 < max_depth);
+            if (!active_e) C.skip(1);
             if (active_e) {
                 DirSample ds;
                 V3 emitted = volpath_sample_emitter(C, si.p, si.n, &si, medium, channel, &ds);
@@ -661,7 +735,7 @@ static void volpath_sample(Ctx &C, Ray ray, int medium, V3 *out, bool *out_valid
                 float bpdf = bsdf_pdf(S, b, si, wo);
                 result += throughput * bsdf_val * mis_weight(ds.pdf, ds.delta ? 0.f : bpdf) * emitted;
             }
-            float s1 = C.next(), s2x = C.next(), s2y = C.next();
+            float s1 = C.next(), s2x, s2y; C.next2(&s2x, &s2y);
             BSDFSample bs; V3 bsdf_val;
             bsdf_sample(S, b, si, s1, s2x, s2y, &bs, &bsdf_val);
             throughput *= bsdf_val;
@@ -724,8 +798,10 @@ static void path_sample(Ctx &C, Ray ray, V3 *out, bool *out_valid) {
         bool active_em = (bsdf_flags(S, b) & F_SMOOTH) != 0;
         DirSample ds; memset((void *) &ds, 0, sizeof(ds));
         V3 em_weight(0.f), wo(0.f);
+        /* path.cpp:246-248: ls.sampler->next_2d() carries no mask and sits in an `if (dr::any_or<true>(active_em))`, which a
+           symbolic loop always traces: every lane in the loop consumes the two numbers, smooth BSDF or not */
+        float sx, sy; C.next2(&sx, &sy);
         if (active_em) {
-            float sx = C.next(), sy = C.next();
             em_weight = sample_emitter_direction(S, si.p, sx, sy, &ds);
             if (ds.pdf != 0.f) {                  /* scene.cpp:361-365: test_visibility */
                 Ray sr = spawn_ray_to(si.p, si.n, ds.p);
@@ -736,7 +812,7 @@ static void path_sample(Ctx &C, Ray ray, V3 *out, bool *out_valid) {
             active_em = ds.pdf != 0.f;
             wo = si.sh.to_local(ds.d);
         }
-        float s1 = C.next(), s2x = C.next(), s2y = C.next();
+        float s1 = C.next(), s2x, s2y; C.next2(&s2x, &s2y);
         V3 bsdf_val = bsdf_eval(S, b, si, wo);
         float bpdf = bsdf_pdf(S, b, si, wo);
         BSDFSample bs; V3 bsdf_weight;
@@ -780,7 +856,7 @@ static inline float hg_dlog_dg(float g, float c) {
 static V3 prb_sample_emitter(Ctx &C, V3 ref_p, V3 ref_n, const SI *ref_si, int medium, uint32_t channel, DirSample *ds_out,
                              bool adjoint, V3 delta_L, V3 adj_emitted, Grads *G) {
     const Scene &S = C.S;
-    float sx = C.next(), sy = C.next();
+    float sx, sy; C.next2(&sx, &sy);
     DirSample ds; V3 emitter_val = sample_emitter_direction(S, ref_p, sx, sy, &ds);
     *ds_out = ds;
     bool active = ds.pdf != 0.f;
@@ -801,6 +877,7 @@ static V3 prb_sample_emitter(Ctx &C, V3 ref_p, V3 ref_n, const SI *ref_si, int m
         bool active_medium = active && medium >= 0, active_surface = active && !active_medium;
         V3 tr_multiplier(1.f);
         float seg_t = 0.f; bool escaped_medium = false;
+        if (!active_medium) C.skip(1);               /* prbvolpath.py:396: the call runs for every lane in the march */
         if (active_medium) {
             (void) C.next();                         /* sample_interaction draw, overwritten below (:399-407) */
             const lrt_medium_desc &M = S.media[medium];
@@ -853,6 +930,7 @@ static void prb_sample(Ctx &C, Ray ray, bool adjoint, V3 delta_L, V3 L_in, V3 *L
         MI mei; mei.t = kInf; mei.wi = -ray.d; mei.p = V3(0.f); mei.medium = medium;
         V3 weight(1.f);
         float seg_t = 0.f; bool in_medium_segment = false;
+        if (!active_medium) C.skip(1);               /* prbvolpath.py:158 */
         if (active_medium) {
             mei = medium_sample_interaction(S, medium, ray, C.next(), channel);
             if (mei.valid()) ray.maxt = mei.t;
@@ -918,8 +996,9 @@ static void prb_sample(Ctx &C, Ray ray, bool adjoint, V3 delta_L, V3 L_in, V3 *L
         bool sample_emitters = act_medium_scatter ? (S.media[medium].sample_emitters != 0) : false;
         if (act_medium_scatter) specular_chain = !sample_emitters;
         bool active_e_medium = act_medium_scatter && sample_emitters;
+        if (!(active_e_surface || active_e_medium)) C.skip(1);        /* prbvolpath.py:365 */
         if (active_e_surface || active_e_medium) {
-            PCG32 nee_rng = C.rng;                    /* sampler.clone(): the adjoint call replays the same numbers */
+            Sampler nee_rng = C.smp;                  /* sampler.clone(): the adjoint call replays the same numbers */
             DirSample ds;
             V3 rp = active_e_medium ? mei.p : si.p, rn = active_e_medium ? V3(0.f) : si.n;
             V3 emitted = prb_sample_emitter(C, rp, rn, active_e_surface ? &si : nullptr, medium, channel, &ds, false, V3(0.f), V3(0.f), nullptr);
@@ -929,11 +1008,11 @@ static void prb_sample(Ctx &C, Ray ray, bool adjoint, V3 delta_L, V3 L_in, V3 *L
             V3 contrib = throughput * nee_weight * mis_weight(ds.pdf, ds.delta ? 0.f : nee_pdf) * emitted;
             L = adjoint ? L - contrib : L + contrib;
             if (adjoint) {
-                PCG32 saved = C.rng; uint64_t ns = C.n_shadow, nn = C.n_shadow_needed;
-                C.rng = nee_rng;
+                Sampler saved = C.smp; uint64_t ns = C.n_shadow, nn = C.n_shadow_needed;
+                C.smp = nee_rng;
                 DirSample ds2;
                 prb_sample_emitter(C, rp, rn, active_e_surface ? &si : nullptr, medium, channel, &ds2, true, delta_L, contrib, G);
-                C.rng = saved; C.n_shadow = ns; C.n_shadow_needed = nn;
+                C.smp = saved; C.n_shadow = ns; C.n_shadow_needed = nn;
                 if (active_e_medium && S.media[medium].phase == LRT_PHASE_HG) {    /* backward(dL * contrib) through phase_val */
                     float dlg = hg_dlog_dg(S.media[medium].g, dot(ds.d, mei.wi));
                     G->g += (double) ((delta_L.x * contrib.x + delta_L.y * contrib.y + delta_L.z * contrib.z) * dlg);
@@ -941,11 +1020,12 @@ static void prb_sample(Ctx &C, Ray ray, bool adjoint, V3 delta_L, V3 L_in, V3 *L
             }
         }
         /* ---- phase function sampling (:299-317) */
+        if (!act_medium_scatter) C.skip(2);          /* prbvolpath.py:294-295 */
         if (act_medium_scatter) {
             valid_ray = true;
             const lrt_medium_desc &M = S.media[medium];
             (void) C.next();
-            float s2x = C.next(), s2y = C.next();
+            float s2x, s2y; C.next2(&s2x, &s2y);
             V3 wo; float phase_pdf; phase_sample(M, mei.wi, s2x, s2y, &wo, &phase_pdf);
             act_medium_scatter = phase_pdf > 0.f;
             if (act_medium_scatter) {
@@ -961,9 +1041,10 @@ static void prb_sample(Ctx &C, Ray ray, bool adjoint, V3 delta_L, V3 L_in, V3 *L
             }
         }
         /* ---- BSDF sampling (:321-349) */
+        if (!active_surface) C.skip(2);              /* prbvolpath.py:317-318 */
         if (active_surface) {
             const lrt_shape_desc &sd = S.shapes[si.shape];
-            float s1 = C.next(), s2x = C.next(), s2y = C.next();
+            float s1 = C.next(), s2x, s2y; C.next2(&s2x, &s2y);
             BSDFSample bs; V3 bsdf_weight;
             bsdf_sample(S, b, si, s1, s2x, s2y, &bs, &bsdf_weight);
             active_surface = bs.pdf > 0.f;
@@ -994,6 +1075,7 @@ static Opts resolve_opts(const Scene &S, const lrt_render_opts *o) {
     r.rr_depth = (o && o->rr_depth >= 0) ? o->rr_depth : S.d.integrator.rr_depth;
     r.hide_emitters = (o && o->hide_emitters >= 0) ? (o->hide_emitters != 0) : (S.d.integrator.hide_emitters != 0);
     r.spp = (o && o->spp) ? o->spp : S.d.sample_count;
+    if (S.d.sampler_type == LRT_SAMPLER_LD) r.spp = ld_round_sample_count(r.spp);      /* integrator.cpp:169-171 */
     r.seed = o ? o->seed : 0;
     return r;
 }
@@ -1004,14 +1086,14 @@ struct SampleOut { float r, g, b, a; float px, py; };
 static SampleOut render_lane(const Scene &S, const Opts &O, uint64_t lane, orc_stats *st) {
     const lrt_film_desc &F = S.d.film;
     Ctx C(S); C.max_depth = O.max_depth; C.rr_depth = O.rr_depth; C.hide_emitters = O.hide_emitters;
-    C.rng = lane_rng(S.d.sampler_seed, O.seed, (uint32_t) lane);
+    C.smp = lane_sampler(S.d.sampler_type, S.d.sampler_seed, O.seed, (uint32_t) lane, O.spp);
     uint32_t idx = (uint32_t) (lane / O.spp);
     uint32_t W = (uint32_t) F.crop_width;
     uint32_t py = idx / W, px = idx - py * W;
     float posx = (float) ((int) px + F.crop_offset_x), posy = (float) ((int) py + F.crop_offset_y);
     float sclx = 1.f / (float) F.crop_width, scly = 1.f / (float) F.crop_height;
     float offx = -(float) F.crop_offset_x * sclx, offy = -(float) F.crop_offset_y * scly;
-    float jx = C.next(), jy = C.next();
+    float jx, jy; C.next2(&jx, &jy);
     float spx = posx + jx, spy = posy + jy;
     float ax = fmaf(spx, sclx, offx), ay = fmaf(spy, scly, offy);
     Ray ray = sample_ray(S, ax, ay);
@@ -1155,7 +1237,7 @@ extern "C" int orc_render_scalar(orc_scene *s, const lrt_render_opts *opts, int 
                 if (lx >= w || ly >= h) continue;
                 Ctx Cx(S); Cx.max_depth = O.max_depth; Cx.rr_depth = O.rr_depth; Cx.hide_emitters = O.hide_emitters;
                 uint32_t sd = O.seed * (uint32_t) (W * H) + (uint32_t) blk * (uint32_t) (bs * bs) + (uint32_t) i;
-                Cx.rng.seed((uint64_t) (S.d.sampler_seed + sd), 0xda3e39cb94b95bdbULL);
+                Cx.smp.rng.seed((uint64_t) (S.d.sampler_seed + sd), 0xda3e39cb94b95bdbULL);
                 float posx = (float) (ox + lx + F.crop_offset_x), posy = (float) (oy + ly + F.crop_offset_y);
                 for (uint32_t k = 0; k < O.spp; ++k) {
                     float jx = Cx.next(), jy = Cx.next();
@@ -1195,6 +1277,13 @@ extern "C" int orc_trace(orc_scene *s, const lrt_rays_soa *rays, const lrt_hits_
 
 /* ---------------------------------------------------------- unit hooks */
 extern "C" void orc_tea32(uint32_t v0, uint32_t v1, int rounds, uint32_t *o0, uint32_t *o1) { tea32(v0, v1, rounds, o0, o1); }
+/* LowDiscrepancySampler::next_1d / next_2d for (sample_index, dimension) of the sequence with the given scramble seed */
+extern "C" void orc_ld_sample(uint32_t sample_count, uint32_t scramble_seed, uint32_t sample_index, uint32_t dim, int two_d, float *out) {
+    Sampler s; s.type = LRT_SAMPLER_LD; s.sample_count = sample_count; s.scramble_seed = scramble_seed; s.sample_index = sample_index; s.dim = dim;
+    if (two_d) s.next2(&out[0], &out[1]); else out[0] = s.next1();
+}
+extern "C" uint32_t orc_ld_round_sample_count(uint32_t spp) { return ld_round_sample_count(spp); }
+extern "C" uint32_t orc_permute(uint32_t i, uint32_t n, uint32_t seed) { return permute_tea(i, n, seed); }
 extern "C" float orc_tea_float32(uint32_t v0, uint32_t v1, int rounds) {   /* random.h:134-139 */
     uint32_t a, b; tea32(v0, v1, rounds, &a, &b); return u2f((b >> 9) | 0x3f800000u) - 1.f;
 }
@@ -1255,10 +1344,10 @@ extern "C" int orc_render_backward(orc_scene *s, const lrt_render_opts *opts, in
     int nt = hw_threads(n_threads);
     auto lane_setup = [&](uint64_t lane, Ctx &C, float *spx, float *spy, Ray *ray) {
         C.max_depth = O.max_depth; C.rr_depth = O.rr_depth; C.hide_emitters = O.hide_emitters;
-        C.rng = lane_rng(S.d.sampler_seed, O.seed, (uint32_t) lane);
+        C.smp = lane_sampler(S.d.sampler_type, S.d.sampler_seed, O.seed, (uint32_t) lane, O.spp);
         uint32_t idx = (uint32_t) (lane / O.spp), py = idx / (uint32_t) W, px = idx - py * (uint32_t) W;
         float posx = (float) ((int) px + F.crop_offset_x), posy = (float) ((int) py + F.crop_offset_y);
-        float jx = C.next(), jy = C.next();
+        float jx, jy; C.next2(&jx, &jy);
         *spx = posx + jx; *spy = posy + jy;
         *ray = sample_ray(S, fmaf(*spx, 1.f / (float) W, -(float) F.crop_offset_x / (float) W), fmaf(*spy, 1.f / (float) H, -(float) F.crop_offset_y / (float) H));
     };
@@ -1298,10 +1387,10 @@ extern "C" int orc_render_backward(orc_scene *s, const lrt_render_opts *opts, in
                     dL = dL + V3(grad_image[p * T] * f, grad_image[p * T + 1] * f, grad_image[p * T + 2] * f);
                 }
             }
-            PCG32 start = C.rng;
+            Sampler start = C.smp;
             V3 L; bool valid;
             prb_sample(C, ray, false, V3(0.f), V3(0.f), &L, &valid, nullptr);
-            C.rng = start; C.n_iter = 0;
+            C.smp = start; C.n_iter = 0;
             V3 L2; Grads g;
             prb_sample(C, ray, true, dL, L, &L2, &valid, &g);
             G[t].add(g);

@@ -44,6 +44,10 @@ def lib():
     L.orc_trace.argtypes = [C.c_void_p, P(_lib.RaysSoA), P(_lib.HitsSoA), C.c_uint32, C.c_int, C.c_int]
     L.orc_tea32.argtypes = [C.c_uint32, C.c_uint32, C.c_int, P(C.c_uint32), P(C.c_uint32)]
     L.orc_tea32.restype = None
+    L.orc_ld_sample.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, P(C.c_float)]
+    L.orc_ld_sample.restype = None
+    L.orc_ld_round_sample_count.argtypes = [C.c_uint32]; L.orc_ld_round_sample_count.restype = C.c_uint32
+    L.orc_permute.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32]; L.orc_permute.restype = C.c_uint32
     L.orc_tea_float32.argtypes = [C.c_uint32, C.c_uint32, C.c_int]
     L.orc_tea_float32.restype = C.c_float
     L.orc_tea_float64.argtypes = [C.c_uint32, C.c_uint32, C.c_int]

@@ -31,6 +31,41 @@ def test_tea_float64_reference_vectors(orc):
         assert L.orc_tea_float64(v0, v1, 4) == expected
 
 
+# src/samplers/tests/test_ldsampler.py:43-77 (test03_ldsampler_deterministic_values): scalar sampler, sample_count 1024,
+# seed(0); ten next_1d, ten next_2d, advance(), ten next_1d, ten next_2d
+LD_1D_S0 = [0.06483602523803711, 0.2767500877380371, 0.006242275238037109, 0.6273360252380371, 0.6273360252380371,
+            0.1634688377380371, 0.3734297752380371, 0.7845625877380371, 0.7415938377380371, 0.4085860252380371]
+LD_2D_S0 = [[0.014822006225585938, 0.06154896318912506], [0.34001731872558594, 0.7011973857879639], [0.7570095062255859, 0.8974864482879639],
+            [0.7374782562255859, 0.8076426982879639], [0.7794704437255859, 0.26174429059028625], [0.5060329437255859, 0.8945567607879639],
+            [0.16911888122558594, 0.6533458232879639], [0.34294700622558594, 0.9521739482879639], [0.16618919372558594, 0.09377552568912506],
+            [0.15935325622558594, 0.44826772809028625]]
+LD_1D_S1 = [0.7005782127380371, 0.9085860252380371, 0.7601485252380371, 0.3939375877380371, 0.4876875877380371,
+            0.6576094627380371, 0.6908125877380371, 0.2113204002380371, 0.4847579002380371, 0.7865157127380371]
+LD_2D_S1 = [[0.8956813812255859, 0.03615833818912506], [0.8400173187255859, 0.20119740068912506], [0.27556419372558594, 0.23440052568912506],
+            [0.026540756225585938, 0.23733021318912506], [0.0021266937255859375, 0.6015880107879639], [0.38884544372558594, 0.6836192607879639],
+            [0.8956813812255859, 0.03615833818912506], [0.9542751312255859, 0.02443958818912506], [0.8409938812255859, 0.9502208232879639],
+            [0.5636501312255859, 0.6650645732879639]]
+
+
+def test_ldsampler_reference_vectors(orc):
+    """The reference's own golden values for LowDiscrepancySampler pin the oracle's sampler (TEA shuffling-network permutation,
+    radical inverse, Sobol' dimension 2, TEA scrambles, dimension counter) bit for bit."""
+    L = orc.lib()
+    v0, v1 = C.c_uint32(), C.c_uint32()
+    L.orc_tea32(0, 0, 4, C.byref(v0), C.byref(v1))            # compute_per_sequence_seed(0): TEA(base_seed 0, sequence 0 + seed 0)
+    out = (C.c_float * 2)()
+    def draw(idx, dim, two):
+        L.orc_ld_sample(1024, v0.value, idx, dim, two, out)
+        return [out[0], out[1]] if two else out[0]
+    for idx, v1d, v2d in ((0, LD_1D_S0, LD_2D_S0), (1, LD_1D_S1, LD_2D_S1)):
+        assert [draw(idx, k, 0) for k in range(10)] == [float(np.float32(x)) for x in v1d]
+        assert [draw(idx, 10 + k, 1) for k in range(10)] == [[float(np.float32(a)), float(np.float32(b))] for a, b in v2d]
+    assert [L.orc_ld_round_sample_count(n) for n in (1, 4, 5, 16, 17, 64, 128, 256, 512, 1000)] == [4, 4, 16, 16, 64, 64, 256, 256, 1024, 1024]
+    for n in (4, 16, 64, 256):                                 # the shuffling network is a bijection for every seed
+        for seed in (0, 1, 0xdeadbeef):
+            assert sorted(L.orc_permute(i, n, seed) for i in range(n)) == list(range(n))
+
+
 def test_pcg32_published_vectors(orc):
     # O'Neill's pcg32-demo: seed(42, 54) -> first six outputs (Dr.Jit's PCG32 is this generator;
     # the reference's own test src/samplers/tests/test_independent.py:21-33 only pins sampler == PCG32)

@@ -119,11 +119,11 @@ def test_liver_volpath_hg_and_params_bit_exact(mi, orc):
 def test_parenchyma_and_multimesh_scenes_bit_exact(mi, orc):
     # Parenchyma: non-spectral medium without emitter sampling, constant emitter, tent filter, hide_emitters
     sc = mi.load_file(PARENCHYMA_XML, integrator="volpath", spp=8, res_width=160, res_height=90, max_depth=65)
-    assert_lanes_equal(sc, orc.OrcScene(sc), 0, 160 * 90 * 8)
+    assert_lanes_equal(sc, orc.OrcScene(sc), 0, 160 * 90 * sc.spp)
     sc = mi.load_file(MULTIMESH_XML, integrator="volpath", spp=8, res_width=160, res_height=90)
-    assert_lanes_equal(sc, orc.OrcScene(sc), 0, 160 * 90 * 8)
+    assert_lanes_equal(sc, orc.OrcScene(sc), 0, 160 * 90 * sc.spp)
     sc = mi.load_file(MULTIMESH_XML, integrator="path", spp=8, res_width=160, res_height=90)
-    assert_lanes_equal(sc, orc.OrcScene(sc), 0, 160 * 90 * 8)
+    assert_lanes_equal(sc, orc.OrcScene(sc), 0, 160 * 90 * sc.spp)
 
 
 def fog_xml(md="12", rf="gaussian", sensor_medium="", exterior="", env=""):
@@ -269,6 +269,34 @@ def test_full_size_c3_properties(mi):
     # two-rank sharding reproduces the image
     a = sc.render(return_raw=True, tile_rank=0, tile_count=2)[1] + sc.render(return_raw=True, tile_rank=1, tile_count=2)[1]
     assert film_close(a, raw).all()
+
+
+# ------------------------------------------------------------ low-discrepancy sampler
+def test_ldsampler_lanes_bit_exact(mi, orc):
+    """src/samplers/ldsampler.cpp (what Parenchyma, GlissonCapsule and Liver-MultiMesh request): the sampler itself is pinned
+    by the reference's golden values (test_oracle_pins.py); here the integrators' dimension bookkeeping on the device
+    must match the oracle's lane for lane, for path, volpath and the PRB primal, and spp is rounded to 4^k."""
+    d = mi.cornell_box(); d['sensor']['sampler'] = {'type': 'ldsampler', 'sample_count': 16}
+    sc = mi.load_dict(d)
+    assert sc.desc.sampler_type == 1 and sc.spp == 16
+    o = orc.OrcScene(sc)
+    for kw in (dict(), dict(integrator="volpath"), dict(spp=5, seed=3), dict(spp=64, max_depth=3, integrator="volpath"), dict(integrator="prbvolpath", seed=1)):
+        spp = {5: 16}.get(kw.get("spp", 16), kw.get("spp", 16))
+        assert_lanes_equal(sc, o, center_lane(sc, spp, 0.3), 1 << 14, **kw)
+    xml = open(LIVER_XML).read().replace('<sampler type="independent">', '<sampler type="ldsampler">')
+    base = os.path.dirname(LIVER_XML)
+    sc = mi.load_string(xml, base_dir=base, integrator="volpath", spp=16, res_width=192, res_height=108)
+    assert sc.desc.sampler_type == 1
+    o = orc.OrcScene(sc)
+    assert_lanes_equal(sc, o, 0, 192 * 108 * 16)
+    p = mi.traverse(sc); p["LiverMedium.phase_function.g"] = 0.6; p.update(); o.param_set("LiverMedium.phase_function.g", 0.6)
+    assert_lanes_equal(sc, o, center_lane(sc, 16), 1 << 15, seed=7, max_depth=30)
+    for path in (PARENCHYMA_XML, MULTIMESH_XML):              # these files name the ld sampler themselves
+        sc = mi.load_file(path, integrator="volpath", spp=10, res_width=160, res_height=90)
+        assert sc.desc.sampler_type == 1 and sc.spp == 16
+        assert_lanes_equal(sc, orc.OrcScene(sc), 0, 160 * 90 * 16)
+    img, raw = sc.render(return_raw=True)
+    assert raw[..., -1].min() > 0 and np.isfinite(img).all()
 
 
 # ------------------------------------------------- kernel variants and accelerators
