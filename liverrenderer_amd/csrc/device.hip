@@ -180,7 +180,7 @@ DeviceScene *device_scene_create(const lrt_scene_desc &d, int device) {
         hipDeviceProp_t prop; HIP_CHECK(hipGetDeviceProperties(&prop, device)); D->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         const size_t n_nodes = bvh.nodes.size() / 16, n_slots = bvh.tris.size() / 12, n_verts = d.n_vertices;
         const size_t nodes_b = n_nodes * 64, verts_b = (n_verts * 16 + 15) & ~size_t(15), tris_b = (n_slots * 8 + 15) & ~size_t(15);
-        D->lds_block = getenv("LRT_LDS_BLOCK") ? atoi(getenv("LRT_LDS_BLOCK")) : 1024; if (D->lds_block != 512) D->lds_block = 1024;
+        D->lds_block = 1024;
         const size_t stack_b = (size_t) 2 * LRT_LDS_STACK * D->lds_block, total = nodes_b + verts_b + tris_b + stack_b;
         const size_t lds_limit = std::min<size_t>((size_t) prop.sharedMemPerBlock ? 160 * 1024 : 64 * 1024, 160 * 1024) - 512;
         if (d.n_faces > 0 && n_verts <= 65535 && n_nodes <= 32767 && n_slots <= 32767 && bvh.max_depth < LRT_LDS_STACK && total <= lds_limit && !getenv("LRT_NO_LDS_BVH")) {
@@ -202,12 +202,12 @@ DeviceScene *device_scene_create(const lrt_scene_desc &d, int device) {
             D->lds.slot_prim = D->track(dev_upload(slot_prim.data(), slot_prim.size(), st));
             D->lds.blob_bytes = (uint32_t) blob.size(); D->lds.nodes_off = 0; D->lds.verts_off = (uint32_t) nodes_b; D->lds.tris_off = (uint32_t) (nodes_b + verts_b);
             D->lds.stack_off = (uint32_t) blob.size(); D->lds.total_bytes = (uint32_t) total;
-            HIP_CHECK(hipFuncSetAttribute((const void *) k_render<LRT_INTEGRATOR_PATH, 1024, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) total));
-            HIP_CHECK(hipFuncSetAttribute((const void *) k_render<LRT_INTEGRATOR_VOLPATH, 1024, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) total));
-            HIP_CHECK(hipFuncSetAttribute((const void *) k_render<LRT_INTEGRATOR_PATH, 512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) total));
-            HIP_CHECK(hipFuncSetAttribute((const void *) k_render<LRT_INTEGRATOR_VOLPATH, 512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) total));
-            HIP_CHECK(hipFuncSetAttribute((const void *) k_render_prb<false, 1024, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) total));
-            HIP_CHECK(hipFuncSetAttribute((const void *) k_render_prb<true, 1024, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) total));
+            #define LRT_SMEM(K) HIP_CHECK(hipFuncSetAttribute((const void *) K, hipFuncAttributeMaxDynamicSharedMemorySize, (int) total))
+            LRT_SMEM((k_render<LRT_INTEGRATOR_PATH, 1024, true, false>)); LRT_SMEM((k_render<LRT_INTEGRATOR_VOLPATH, 1024, true, false>));
+            LRT_SMEM((k_render<LRT_INTEGRATOR_PATH, 1024, true, true>)); LRT_SMEM((k_render<LRT_INTEGRATOR_VOLPATH, 1024, true, true>));
+            LRT_SMEM((k_render_prb<false, 1024, true, false>)); LRT_SMEM((k_render_prb<true, 1024, true, false>));
+            LRT_SMEM((k_render_prb<false, 1024, true, true>)); LRT_SMEM((k_render_prb<true, 1024, true, true>));
+            #undef LRT_SMEM
             D->use_lds = true;
         }
     }
@@ -469,8 +469,10 @@ static void launch_prb(DeviceScene *D, const DRenderParams &rp, const PoolGeomet
                        float4 *L_buf, const float *grad_image, double *grads, float *film, float *sample_out) {
     hipStream_t st = D->stream;
     HIP_CHECK(hipMemsetAsync(&D->counters->next_lane, 0, sizeof(unsigned long long), st));
-    if (D->use_lds) k_render_prb<ADJOINT, 1024, true><<<g.n_wg, 1024, g.smem, st>>>(D->sc, rp, D->lds, D->q[0], D->q[1], D->dl[0], D->dl[1], g.P, D->counters, pixel_list, lane_begin, L_buf, grad_image, D->wfilm, grads, film, sample_out, lane_begin);
-    else k_render_prb<ADJOINT, LRT_BLOCK, false><<<g.n_wg, LRT_BLOCK, g.smem, st>>>(D->sc, rp, D->lds, D->q[0], D->q[1], D->dl[0], D->dl[1], g.P, D->counters, pixel_list, lane_begin, L_buf, grad_image, D->wfilm, grads, film, sample_out, lane_begin);
+    #define LRT_LAUNCH_PRB(BS, LDSB, LD) k_render_prb<ADJOINT, BS, LDSB, LD><<<g.n_wg, BS, g.smem, st>>>(D->sc, rp, D->lds, D->q[0], D->q[1], D->dl[0], D->dl[1], g.P, D->counters, pixel_list, lane_begin, L_buf, grad_image, D->wfilm, grads, film, sample_out, lane_begin)
+    if (D->use_lds) { if (rp.ld_count) LRT_LAUNCH_PRB(1024, true, true); else LRT_LAUNCH_PRB(1024, true, false); }
+    else { if (rp.ld_count) LRT_LAUNCH_PRB(LRT_BLOCK, false, true); else LRT_LAUNCH_PRB(LRT_BLOCK, false, false); }
+    #undef LRT_LAUNCH_PRB
     HIP_CHECK(hipGetLastError());
 }
 
@@ -498,13 +500,10 @@ static void run_wavefront(DeviceScene *D, const lrt_scene_desc &d, const Resolve
     HIP_CHECK(hipEventRecord(a, st));
     if (prb) launch_prb<false>(D, rp, g, pixel_list, lane_begin, nullptr, nullptr, nullptr, film, sample_out);
     else {
-        #define LRT_LAUNCH(I, BS, LDSB) k_render<I, BS, LDSB><<<g.n_wg, BS, g.smem, st>>>(D->sc, rp, D->lds, D->q[0], D->q[1], g.P, D->counters, pixel_list, lane_begin, film, sample_out, lane_begin)
-        if (D->use_lds) {
-            if (D->lds_block == 512) { if (isp) LRT_LAUNCH(LRT_INTEGRATOR_PATH, 512, true); else LRT_LAUNCH(LRT_INTEGRATOR_VOLPATH, 512, true); }
-            else { if (isp) LRT_LAUNCH(LRT_INTEGRATOR_PATH, 1024, true); else LRT_LAUNCH(LRT_INTEGRATOR_VOLPATH, 1024, true); }
-        } else {
-            if (isp) LRT_LAUNCH(LRT_INTEGRATOR_PATH, LRT_BLOCK, false); else LRT_LAUNCH(LRT_INTEGRATOR_VOLPATH, LRT_BLOCK, false);
-        }
+        #define LRT_LAUNCH(I, BS, LDSB) do { if (rp.ld_count) k_render<I, BS, LDSB, true><<<g.n_wg, BS, g.smem, st>>>(D->sc, rp, D->lds, D->q[0], D->q[1], g.P, D->counters, pixel_list, lane_begin, film, sample_out, lane_begin); \
+                                             else k_render<I, BS, LDSB, false><<<g.n_wg, BS, g.smem, st>>>(D->sc, rp, D->lds, D->q[0], D->q[1], g.P, D->counters, pixel_list, lane_begin, film, sample_out, lane_begin); } while (0)
+        if (D->use_lds) { if (isp) LRT_LAUNCH(LRT_INTEGRATOR_PATH, 1024, true); else LRT_LAUNCH(LRT_INTEGRATOR_VOLPATH, 1024, true); }
+        else { if (isp) LRT_LAUNCH(LRT_INTEGRATOR_PATH, LRT_BLOCK, false); else LRT_LAUNCH(LRT_INTEGRATOR_VOLPATH, LRT_BLOCK, false); }
         #undef LRT_LAUNCH
         HIP_CHECK(hipGetLastError());
     }

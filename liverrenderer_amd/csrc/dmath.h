@@ -259,9 +259,12 @@ DEV void tea32_rounds2(uint32_t v0, uint32_t v1, uint32_t *o0, uint32_t *o1) {
 //    (include/mitsuba/core/qmc.h:189-252) with TEA scrambles.  EVERY call the traced loop body contains bumps the
 //    counter of every lane that is in the loop, whatever the call's mask; skip() stands for the calls a lane's own
 //    control flow does not reach.  Layout: state = dimension counter, inc = scramble_seed | sample_index << 32.
-struct PCG32 {
+// LD is a compile-time switch (separate kernel instantiations) so that the independent sampler's hot path carries no
+// trace of the other mode.
+template <bool LD>
+struct SamplerT {
     uint64_t state, inc;
-    uint32_t ld_count;         // wave-uniform: 0 = independent, else the ld sampler's (rounded) sample count
+    uint32_t ld_count;         // LD: the sampler's (rounded) sample count, wave-uniform
     DEV uint32_t next_u32() {
         uint64_t old = state;
         state = old * 0x5851f42d4c957f2dULL + inc;
@@ -288,7 +291,7 @@ struct PCG32 {
         return (float) scramble / 4294967296.f;
     }
     DEV float next() {
-        if (ld_count) {
+        if (LD) {
             const uint32_t i = ld_point();
             uint32_t s0, s1; tea32((uint32_t) inc, 0x48bc48ebu, &s0, &s1);
             return radical_inverse_2(i, s0);
@@ -296,7 +299,7 @@ struct PCG32 {
         return u2f((next_u32() >> 9) | 0x3f800000u) - 1.f;
     }
     DEV void next2(float &x, float &y) {
-        if (ld_count) {
+        if (LD) {
             const uint32_t i = ld_point();
             uint32_t sx, sy; tea32((uint32_t) inc, 0x98bc51abu, &sx, &sy);
             x = radical_inverse_2(i, sx); y = sobol_2(i, sy);
@@ -304,10 +307,11 @@ struct PCG32 {
         }
         x = u2f((next_u32() >> 9) | 0x3f800000u) - 1.f; y = u2f((next_u32() >> 9) | 0x3f800000u) - 1.f;
     }
-    DEV void skip(uint32_t n) { if (ld_count) state += n; }
+    DEV void skip(uint32_t n) { if (LD) state += n; }
     DEV void seed(uint64_t initstate, uint64_t initseq) {
         state = 0; inc = (initseq << 1) | 1u; next_u32(); state += initstate; next_u32();
     }
 };
+typedef SamplerT<false> PCG32;
 
 } // namespace lrt

@@ -38,8 +38,9 @@ DEV void store_state(const DPathStreams &q, uint32_t i, const PathState &s) {
 // Sampler::seed in the JIT branch of SamplingIntegrator::render (integrator.cpp:308-311): independent: TEA4(base + seed,
 // lane) seeds the PCG32 stream (sampler.cpp:129-148); ld: the sequence is the lane's pixel, scramble seed =
 // TEA4(base, spp * pixel + seed).first (sampler.cpp:97-107), sample index = lane % spp (:109-117).
+template <bool LD>
 DEV uint64_t lane_rng_inc(const DRenderParams &rp, uint32_t lane) {
-    if (rp.ld_count) {
+    if (LD) {
         const uint32_t pixel = (rp.log2_spp != 0xffffffffu) ? (lane >> rp.log2_spp) : (lane / rp.spp);
         uint32_t v0, v1; tea32(rp.base_seed, rp.spp * pixel + rp.seed, &v0, &v1);
         return (uint64_t) v0 | ((uint64_t) (lane - pixel * rp.spp) << 32);
@@ -47,14 +48,21 @@ DEV uint64_t lane_rng_inc(const DRenderParams &rp, uint32_t lane) {
     uint32_t v0, v1; tea32(rp.seed_value, lane, &v0, &v1);
     return ((uint64_t) v1 << 1) | 1u;
 }
-DEV PCG32 lane_rng_fresh(const DRenderParams &rp, uint32_t lane) {
-    PCG32 r; r.ld_count = rp.ld_count;
-    if (rp.ld_count) { r.state = 0; r.inc = lane_rng_inc(rp, lane); return r; }
+template <bool LD>
+DEV SamplerT<LD> lane_rng_fresh(const DRenderParams &rp, uint32_t lane) {
+    SamplerT<LD> r; r.ld_count = rp.ld_count;
+    if (LD) { r.state = 0; r.inc = lane_rng_inc<LD>(rp, lane); return r; }
     uint32_t v0, v1; tea32(rp.seed_value, lane, &v0, &v1);
     r.seed(v0, v1); return r;
 }
-DEV PCG32 lane_rng_resume(const DRenderParams &rp, uint32_t lane, uint64_t state) {
-    PCG32 r; r.ld_count = rp.ld_count; r.state = state; r.inc = lane_rng_inc(rp, lane); return r;
+template <bool LD>
+DEV SamplerT<LD> lane_rng_resume(const DRenderParams &rp, uint32_t lane, uint64_t state) {
+    SamplerT<LD> r; r.ld_count = rp.ld_count; r.state = state; r.inc = lane_rng_inc<LD>(rp, lane); return r;
+}
+// the pixel jitter: the sampler's first 2-D sample (integrator.cpp:465), needed again wherever a film footprint is formed
+DEV void lane_jitter(const DRenderParams &rp, uint32_t lane, float &jx, float &jy) {
+    if (rp.ld_count) { SamplerT<true> r = lane_rng_fresh<true>(rp, lane); r.next2(jx, jy); }
+    else { SamplerT<false> r = lane_rng_fresh<false>(rp, lane); r.next2(jx, jy); }
 }
 
 // lane -> pixel (src/render/integrator.cpp:321-338); tile-sharded renders go
@@ -86,11 +94,12 @@ DEV Ray camera_ray(const DScene &sc, float ax, float ay) {
 
 // A fresh camera path for rank-local lane index j (integrator.cpp:321-338,449-470; volpath.cpp:93-140 /
 // path.cpp:95-170 up to the loop).
+template <bool LD>
 DEV PathState generate_camera_path(const DScene &sc, const DRenderParams &rp, const uint32_t *__restrict__ pixel_list, uint64_t j) {
     uint32_t lane;
     if (pixel_list) { uint32_t pj = (uint32_t) (j / rp.spp); lane = pixel_list[pj] * rp.spp + (uint32_t) (j - (uint64_t) pj * rp.spp); }
     else lane = (uint32_t) j;
-    PCG32 rng = lane_rng_fresh(rp, lane);
+    SamplerT<LD> rng = lane_rng_fresh<LD>(rp, lane);
     int px, py; lane_to_pixel(sc, rp, lane, &px, &py);
     float jx, jy; rng.next2(jx, jy);
     float spx = (float) px + jx, spy = (float) py + jy;
@@ -151,8 +160,7 @@ DEV void finish_path(const DScene &sc, const DRenderParams &rp, float *__restric
         if (F.has_alpha) { atomicAdd(p + 3, alpha); atomicAdd(p + 4, 1.f); } else atomicAdd(p + 3, 1.f);
         return;
     }
-    PCG32 rng = lane_rng_fresh(rp, lane);                                 // the pixel jitter is the stream's first two draws
-    float jx, jy; rng.next2(jx, jy);
+    float jx, jy; lane_jitter(rp, lane, jx, jy);
     float spx = (float) px + jx, spy = (float) py + jy;
     int n = F.fn, count = F.fcount;
     int pix = (int) __builtin_floorf(spx) - n, piy = (int) __builtin_floorf(spy) - n;
@@ -217,8 +225,8 @@ DEV void finish_paths_wave(const DScene &sc, const DRenderParams &rp, float *__r
 
 // ---------------------------------------------------------- volpath NEE
 // src/integrators/volpath.cpp:400-554.  ref_n is zero for medium interactions.
-template <typename TR>
-DEV V3 volpath_sample_emitter(const DScene &sc, PCG32 &rng, V3 ref_p, V3 ref_n, bool ref_is_surface, uint32_t ref_shape, V3 ref_geo_n,
+template <typename SMP, typename TR>
+DEV V3 volpath_sample_emitter(const DScene &sc, SMP &rng, V3 ref_p, V3 ref_n, bool ref_is_surface, uint32_t ref_shape, V3 ref_geo_n,
                               int medium, uint32_t channel, DirSample *ds_out, const TR &tr, uint32_t &n_shadow) {
     V3 transmittance(1.f);
     float sx, sy; rng.next2(sx, sy);
@@ -289,8 +297,8 @@ DEV V3 volpath_sample_emitter(const DScene &sc, PCG32 &rng, V3 ref_p, V3 ref_n, 
 
 // One trip of volpath's while_loop (src/integrators/volpath.cpp:170-391).
 // Returns true when the path survives.
-template <typename TR>
-DEV bool volpath_iteration(const DScene &sc, const DRenderParams &rp, PathState &s, PCG32 &rng, const TR &tr, uint32_t &n_shadow, uint32_t &n_extra) {
+template <typename SMP, typename TR>
+DEV bool volpath_iteration(const DScene &sc, const DRenderParams &rp, PathState &s, SMP &rng, const TR &tr, uint32_t &n_shadow, uint32_t &n_extra) {
     uint32_t depth = s.flags & PF_DEPTH_MASK;
     const bool proven_empty = (s.flags & PF_NOHIT) != 0;
     int medium = (int) ((s.flags & PF_MEDIUM_MASK) >> PF_MEDIUM_SHIFT) - 1;
@@ -367,7 +375,7 @@ DEV bool volpath_iteration(const DScene &sc, const DRenderParams &rp, PathState 
             // density can be 0 (which would skip the third draw); everything else takes the full routine.
             bool rejected = false;
             if (sc.nee_fast_reject) {
-                PCG32 saved = rng;
+                SMP saved = rng;
                 float sx, sy; rng.next2(sx, sy);                        // the emitter sample, then the march's single draw
                 float u3 = rng.next();
                 const float lo = 9.5367431640625e-7f, hi = 1.f - 9.5367431640625e-7f;
@@ -459,7 +467,7 @@ DEV bool volpath_iteration(const DScene &sc, const DRenderParams &rp, PathState 
     uint32_t nohit = 0;
 #ifdef LRT_EXPERIMENT
     if (active && (rp.profile & 0x40000u) && medium >= 0 && sc.grid.enabled) {
-        PCG32 pk = rng; (void) pk.next();
+        SMP pk = rng; (void) pk.next();
         const DMedium M = sc.media[medium];
         Ray r2 = ray; r2.o.x += 1e-30f;
         MI m2 = medium_sample_interaction(M, r2, pk.next(), channel);
@@ -467,7 +475,7 @@ DEV bool volpath_iteration(const DScene &sc, const DRenderParams &rp, PathState 
     }
 #endif
     if (active) {
-        PCG32 pk = rng;
+        SMP pk = rng;
         bool a2 = any_nonzero(throughput);
         float q2 = fmin_(max3(throughput) * sqr(eta), .95f);
         if (a2) { float u = pk.next(); a2 = (u < q2) || !(depth > (uint32_t) rp.rr_depth); }
@@ -487,8 +495,8 @@ DEV bool volpath_iteration(const DScene &sc, const DRenderParams &rp, PathState 
 // One trip of path's while_loop (src/integrators/path.cpp:194-338); the
 // ray_intersect_preliminary of the previous trip (:332-337, or :164-169 for the
 // first one) is the trace at the top.
-template <typename TR>
-DEV bool path_iteration(const DScene &sc, const DRenderParams &rp, PathState &s, PCG32 &rng, const TR &tr, uint32_t &n_shadow) {
+template <typename SMP, typename TR>
+DEV bool path_iteration(const DScene &sc, const DRenderParams &rp, PathState &s, SMP &rng, const TR &tr, uint32_t &n_shadow) {
     uint32_t depth = s.flags & PF_DEPTH_MASK;
     bool prev_bsdf_delta = (s.flags & PF_SPECULAR) != 0, valid_ray = (s.flags & PF_VALID) != 0;
     const uint32_t max_depth = (uint32_t) rp.max_depth;
@@ -610,7 +618,7 @@ DEV void retire_and_compact_wave(const DScene &sc, const DRenderParams &rp, bool
     }
 }
 
-template <int INTEGRATOR, int BLOCK, bool LDS_BVH>
+template <int INTEGRATOR, int BLOCK, bool LDS_BVH, bool LD>
 __global__ void __launch_bounds__(BLOCK)
 k_render(DScene sc, DRenderParams rp, DLdsInfo li, DPathStreams q0, DPathStreams q1, uint32_t P, DCounters *__restrict__ cnt,
          const uint32_t *__restrict__ pixel_list, uint64_t lane_begin, float *__restrict__ film, float *__restrict__ sample_out, uint64_t sample_base) {
@@ -668,7 +676,7 @@ k_render(DScene sc, DRenderParams rp, DLdsInfo li, DPathStreams q0, DPathStreams
             } else {
                 const uint32_t i = ((t - ta - tc - tb) << 6) + lane_in_wave;
                 had_path = i < fresh;
-                if (had_path) s = generate_camera_path(sc, rp, pixel_list, lane_begin + fresh_base + i);
+                if (had_path) s = generate_camera_path<LD>(sc, rp, pixel_list, lane_begin + fresh_base + i);
             }
 #ifdef LRT_EXPERIMENT
             const PathState s_saved = s;
@@ -682,7 +690,7 @@ k_render(DScene sc, DRenderParams rp, DLdsInfo li, DPathStreams q0, DPathStreams
             } else
 #endif
             if (had_path) {
-                PCG32 rng = lane_rng_resume(rp, s.lane, s.rng_state);
+                SamplerT<LD> rng = lane_rng_resume<LD>(rp, s.lane, s.rng_state);
                 if (INTEGRATOR == LRT_INTEGRATOR_PATH) alive = LDS_BVH ? path_iteration(sc, rp, s, rng, tr_lds, n_shadow) : path_iteration(sc, rp, s, rng, tr_glb, n_shadow);
                 else alive = LDS_BVH ? volpath_iteration(sc, rp, s, rng, tr_lds, n_shadow, n_extra) : volpath_iteration(sc, rp, s, rng, tr_glb, n_shadow, n_extra);
                 s.rng_state = rng.state;
@@ -695,7 +703,7 @@ k_render(DScene sc, DRenderParams rp, DLdsInfo li, DPathStreams q0, DPathStreams
                 if ((rp.profile >> (8 + kind)) & 1u) {
                     PathState s2 = s_saved; bool alive2 = false; uint32_t d0 = 0, d1 = 0;
                     if (had_path) {
-                        PCG32 rng = lane_rng_resume(rp, s2.lane, s2.rng_state);
+                        SamplerT<LD> rng = lane_rng_resume<LD>(rp, s2.lane, s2.rng_state);
                         if (INTEGRATOR == LRT_INTEGRATOR_PATH) alive2 = LDS_BVH ? path_iteration(sc, rp, s2, rng, tr_lds, d0) : path_iteration(sc, rp, s2, rng, tr_glb, d0);
                         else alive2 = LDS_BVH ? volpath_iteration(sc, rp, s2, rng, tr_lds, d0, d1) : volpath_iteration(sc, rp, s2, rng, tr_glb, d0, d1);
                     }
@@ -787,9 +795,8 @@ k_splat_lanes(DScene sc, DRenderParams rp, const float4 *__restrict__ lane_L, co
         const float4 v = lane_L[i];
         L = V3(v.x, v.y, v.z); alpha = v.w;
         if (rp.integrator == LRT_INTEGRATOR_PATH && alpha == 0.f) L = V3(0.f);         // path.cpp:342-345
-        PCG32 rng = lane_rng_fresh(rp, lane);                                 // the pixel jitter is the stream's first two draws
         int px, py; lane_to_pixel(sc, rp, lane, &px, &py);
-        float jx, jy; rng.next2(jx, jy);
+        float jx, jy; lane_jitter(rp, lane, jx, jy);
         float spx = (float) px + jx, spy = (float) py + jy;
         pix = (int) __builtin_floorf(spx) - F.fn; piy = (int) __builtin_floorf(spy) - F.fn;
         relx = (float) pix + .5f - spx; rely = (float) piy + .5f - spy;

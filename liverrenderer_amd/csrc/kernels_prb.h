@@ -23,8 +23,8 @@ DEV float hg_dlog_dg(float g, float c) {
 
 // prbvolpath.py:354-444.  Returns emitter_val * transmittance; seg_sum[c] accumulates -t_seg * scale over the
 // medium segments the reference backpropagates through (segments that end on a surface with tr_c > 0, :425-427).
-template <typename TR>
-DEV V3 prb_sample_emitter(const DScene &sc, PCG32 &rng, V3 ref_p, V3 ref_n, bool ref_is_surface, uint32_t ref_shape, V3 ref_geo_n,
+template <typename SMP, typename TR>
+DEV V3 prb_sample_emitter(const DScene &sc, SMP &rng, V3 ref_p, V3 ref_n, bool ref_is_surface, uint32_t ref_shape, V3 ref_geo_n,
                           int medium, uint32_t channel, DirSample *ds_out, const TR &tr, uint32_t &n_shadow, V3 *seg_sum) {
     float sx, sy; rng.next2(sx, sy);
     DirSample ds; V3 emitter_val = sample_emitter_direction(sc, ref_p, sx, sy, &ds);
@@ -78,8 +78,8 @@ DEV V3 prb_sample_emitter(const DScene &sc, PCG32 &rng, V3 ref_p, V3 ref_n, bool
 
 // One trip of prbvolpath's loop (prbvolpath.py:139-349).  s.res holds L: accumulated radiance (primal) or the
 // radiance still to be collected (adjoint).  Returns true when the path survives.
-template <bool ADJOINT, typename TR>
-DEV bool prb_iteration(const DScene &sc, const DRenderParams &rp, PathState &s, PCG32 &rng, const TR &tr, uint32_t &n_shadow,
+template <bool ADJOINT, typename SMP, typename TR>
+DEV bool prb_iteration(const DScene &sc, const DRenderParams &rp, PathState &s, SMP &rng, const TR &tr, uint32_t &n_shadow,
                        V3 delta_L, PrbGrads &G) {
     uint32_t depth = s.flags & PF_DEPTH_MASK;
     int medium = (int) ((s.flags & PF_MEDIUM_MASK) >> PF_MEDIUM_SHIFT) - 1;
@@ -232,9 +232,8 @@ DEV bool prb_iteration(const DScene &sc, const DRenderParams &rp, PathState &s, 
 
 // Filter footprint helpers shared by the weight-film and delta_L kernels (imageblock.cpp:431-500)
 DEV void lane_sample_pos(const DScene &sc, const DRenderParams &rp, uint32_t lane, float *spx, float *spy, int *px, int *py) {
-    PCG32 rng = lane_rng_fresh(rp, lane);
     lane_to_pixel(sc, rp, lane, px, py);
-    float jx, jy; rng.next2(jx, jy);
+    float jx, jy; lane_jitter(rp, lane, jx, jy);
     *spx = (float) *px + jx; *spy = (float) *py + jy;
 }
 
@@ -299,7 +298,7 @@ DEV V3 lane_delta_L(const DScene &sc, const DRenderParams &rp, uint32_t lane, co
 //                   splat into the film / sample_out when L_buf is null (lrt_render with integrator prbvolpath).
 // ADJOINT == true : replay; finished lanes only retire; the parameter gradients of a tile are summed inside the wave,
 //                   accumulated per workgroup in f64 (LDS) and added to grads[7] once at the end.
-template <bool ADJOINT, int BLOCK, bool LDS_BVH>
+template <bool ADJOINT, int BLOCK, bool LDS_BVH, bool LD>
 __global__ void __launch_bounds__(BLOCK)
 k_render_prb(DScene sc, DRenderParams rp, DLdsInfo li, DPathStreams q0, DPathStreams q1, float4 *__restrict__ dl0, float4 *__restrict__ dl1, uint32_t P,
              DCounters *__restrict__ cnt, const uint32_t *__restrict__ pixel_list, uint64_t lane_begin,
@@ -361,7 +360,7 @@ k_render_prb(DScene sc, DRenderParams rp, DLdsInfo li, DPathStreams q0, DPathStr
                 had_path = i < fresh;
                 if (had_path) {                                // common.py:231-309 + prbvolpath.py:113-137
                     const unsigned long long slot = fresh_base + i;
-                    s = generate_camera_path(sc, rp, pixel_list, lane_begin + slot);
+                    s = generate_camera_path<LD>(sc, rp, pixel_list, lane_begin + slot);
                     s.flags = PF_SPECULAR | (s.flags & (3u << PF_CHANNEL_SHIFT));      // valid_ray = false, specular_chain = true, medium = none
                     V3 dL(0.f);
                     if (ADJOINT) { float4 l = L_buf[slot]; s.res = V3(l.x, l.y, l.z); dL = lane_delta_L(sc, rp, s.lane, grad_image, wfilm); }
@@ -370,7 +369,7 @@ k_render_prb(DScene sc, DRenderParams rp, DLdsInfo li, DPathStreams q0, DPathStr
             }
             PrbGrads G; G.sigma_t[0] = G.sigma_t[1] = G.sigma_t[2] = G.albedo[0] = G.albedo[1] = G.albedo[2] = G.g = 0.f;
             if (had_path) {
-                PCG32 rng = lane_rng_resume(rp, s.lane, s.rng_state);
+                SamplerT<LD> rng = lane_rng_resume<LD>(rp, s.lane, s.rng_state);
                 alive = LDS_BVH ? prb_iteration<ADJOINT>(sc, rp, s, rng, tr_lds, n_shadow, V3(dl.x, dl.y, dl.z), G)
                                 : prb_iteration<ADJOINT>(sc, rp, s, rng, tr_glb, n_shadow, V3(dl.x, dl.y, dl.z), G);
                 s.rng_state = rng.state;
