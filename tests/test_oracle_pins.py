@@ -350,6 +350,21 @@ def test_prb_gradients_match_finite_differences(mi, orc, case):
     assert (g["albedo"] > 0).all() and (g["sigma_t"] < 0).all()
 
 
+def test_ldsampler_render_agrees_with_independent(mi, orc):
+    """Integrator-level sanity of the low-discrepancy sampler (no render fixture exists in the reference tree for it):
+    the ld estimate agrees with the independent one in expectation, for path, volpath and the PRB primal."""
+    xi = prb_scene_xml("null", PRB_AREA, res=8)
+    xl = xi.replace('<sampler type="independent">', '<sampler type="ldsampler">')
+    si, sl = mi.load_string(xi), mi.load_string(xl)
+    oi, ol = orc.OrcScene(si), orc.OrcScene(sl)
+    assert sl.desc.sampler_type == 1 and sl.spp == 4
+    for integ in ("path", "volpath", "prbvolpath"):
+        a = oi.render(spp=4096, seed=5, integrator=integ).astype(np.float64)[..., :3]
+        b = ol.render(spp=4096, seed=5, integrator=integ).astype(np.float64)[..., :3]
+        assert abs(a.mean() - b.mean()) <= 0.02 * a.mean(), (integ, a.mean(), b.mean())
+        assert np.abs(a - b).mean() <= 0.08 * a.mean()
+
+
 def test_prb_primal_matches_volpath_in_expectation(mi, orc):
     """prbvolpath's primal estimator (RR clamp .99, analytic NEE transmittance) and volpath estimate the same image."""
     sc = mi.load_string(prb_scene_xml("null", PRB_AREA)); o = orc.OrcScene(sc)

@@ -342,12 +342,13 @@ def test_error_reporting(mi, cornell):
 from test_oracle_pins import prb_scene_xml, PRB_ENV, PRB_AREA
 
 
-@pytest.mark.parametrize("case", ["null+area", "dielectric+env", "tent"])
+@pytest.mark.parametrize("case", ["null+area", "dielectric+env", "tent", "ldsampler"])
 def test_prb_primal_lanes_and_gradients(mi, orc, case):
     """prbvolpath primal lanes bit-exact; adjoint gradients equal to the oracle's up to summation order
     (float partial sums per workgroup vs. double per lane: 2e-4 relative to the gradient's scale)."""
     if case == "null+area": xml = prb_scene_xml("null", PRB_AREA, res=16)
     elif case == "dielectric+env": xml = prb_scene_xml("dielectric", PRB_ENV, res=16)
+    elif case == "ldsampler": xml = prb_scene_xml("null", PRB_AREA, res=16).replace('<sampler type="independent">', '<sampler type="ldsampler">')
     else: xml = prb_scene_xml("null", PRB_AREA, rf="tent", res=16)
     sc = mi.load_string(xml); o = orc.OrcScene(sc)
     spp = 64
