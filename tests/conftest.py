@@ -11,6 +11,7 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 SCENES = os.path.join(ROOT, "scenes")
 LIVER_XML = os.path.join(SCENES, "Liver-SingleMesh", "mitsuba3", "scene.xml")
 PARENCHYMA_XML = os.path.join(SCENES, "Parenchyma", "mitsuba3", "scene.xml")
+GLISSON_XML = os.path.join(SCENES, "GlissonCapsule", "mitsuba3", "scene.xml")
 MULTIMESH_XML = os.path.join(SCENES, "Liver-MultiMesh", "mitsuba3", "scene.xml")
 
 

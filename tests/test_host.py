@@ -8,7 +8,7 @@ import re
 import numpy as np
 import pytest
 
-from conftest import ROOT, LIVER_XML, PARENCHYMA_XML, MULTIMESH_XML
+from conftest import GLISSON_XML, ROOT, LIVER_XML, PARENCHYMA_XML, MULTIMESH_XML
 
 
 def test_library_exports_every_declared_symbol(mi):
@@ -156,6 +156,9 @@ def test_other_scene_files_load(mi):
     assert p.bsdfs[p.shapes[0].bsdf].eta == pytest.approx(1.38)
     etas = sorted(p.bsdfs[i].eta for i in range(p.n_bsdfs) if p.bsdfs[i].type == 1)
     assert etas[-1] == pytest.approx(1.5046 / 1.000277)           # <bsdf type="dielectric"/>: bk7 / air (include/mitsuba/render/ior.h)
+    sg = mi.load_file(GLISSON_XML, integrator="volpath"); g = sg.desc          # src/media/glissonCapsule.cpp:142-144,196-197
+    assert g.media[0].has_spectral_extinction == 1 and g.media[0].sample_emitters == 1 and g.sampler_type == 1 and g.sample_count == 64
+    assert (g.film.width, g.film.height, g.film.rfilter) == (1280, 720, 2) and g.integrator.max_depth == 65
     sm = mi.load_file(MULTIMESH_XML, integrator="path"); m = sm.desc
     assert m.n_faces == 2400 and m.shapes[0].interior_medium == -1
 

@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import LIVER_XML, PARENCHYMA_XML, MULTIMESH_XML, ROOT
+from conftest import LIVER_XML, PARENCHYMA_XML, MULTIMESH_XML, GLISSON_XML, ROOT
 from test_oracle_pins import _stairs, stairs_rays, _cube
 
 pytestmark = pytest.mark.gpu
@@ -291,7 +291,7 @@ def test_ldsampler_lanes_bit_exact(mi, orc):
     assert_lanes_equal(sc, o, 0, 192 * 108 * 16)
     p = mi.traverse(sc); p["LiverMedium.phase_function.g"] = 0.6; p.update(); o.param_set("LiverMedium.phase_function.g", 0.6)
     assert_lanes_equal(sc, o, center_lane(sc, 16), 1 << 15, seed=7, max_depth=30)
-    for path in (PARENCHYMA_XML, MULTIMESH_XML):              # these files name the ld sampler themselves
+    for path in (PARENCHYMA_XML, MULTIMESH_XML, GLISSON_XML):  # these files name the ld sampler themselves
         sc = mi.load_file(path, integrator="volpath", spp=10, res_width=160, res_height=90)
         assert sc.desc.sampler_type == 1 and sc.spp == 16
         assert_lanes_equal(sc, orc.OrcScene(sc), 0, 160 * 90 * 16)
