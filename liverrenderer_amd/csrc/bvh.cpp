@@ -39,6 +39,7 @@ struct Builder {
             const float *p0 = pos + 3 * faces[3 * f], *p1 = pos + 3 * faces[3 * f + 1], *p2 = pos + 3 * faces[3 * f + 2];
             float t[12] = { p0[0], p0[1], p0[2], 0.f, p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2], 0.f, p2[0] - p0[0], p2[1] - p0[1], p2[2] - p0[2], 0.f };
             memcpy(&t[3], &f, 4);
+            if (i + 1 == e) t[7] = 1.f;                 // e1.w: last triangle of the leaf (while-while traversal)
             out.tris.insert(out.tris.end(), t, t + 12);
         }
         *count = e - b;

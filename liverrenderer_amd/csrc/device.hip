@@ -207,6 +207,7 @@ DeviceScene *device_scene_create(const lrt_scene_desc &d, int device) {
             LRT_SMEM((k_render<LRT_INTEGRATOR_PATH, 1024, true, true>)); LRT_SMEM((k_render<LRT_INTEGRATOR_VOLPATH, 1024, true, true>));
             LRT_SMEM((k_render_prb<false, 1024, true, false>)); LRT_SMEM((k_render_prb<true, 1024, true, false>));
             LRT_SMEM((k_render_prb<false, 1024, true, true>)); LRT_SMEM((k_render_prb<true, 1024, true, true>));
+            LRT_SMEM((k_trace_lds<true>)); LRT_SMEM((k_trace_lds<false>));
             #undef LRT_SMEM
             D->use_lds = true;
         }
@@ -603,7 +604,11 @@ void device_trace(DeviceScene *D, const lrt_rays_soa *rays, const lrt_hits_soa *
         float *t = mk(), *u = mk(), *v = mk(); uint32_t *prim = (uint32_t *) mk();
         uint32_t grid = (n + LRT_BLOCK - 1) / LRT_BLOCK;
         if (n) {
-            if (any_hit) k_trace<true><<<grid, LRT_BLOCK, 0, st>>>(D->sc, ox, oy, oz, dx, dy, dz, tm, t, u, v, prim, n);
+            if (D->use_lds) {                     // the render kernels' tracer: BVH image in LDS
+                const uint32_t g = std::min<uint32_t>((uint32_t) D->n_cus, (n + 1023) / 1024);
+                if (any_hit) k_trace_lds<true><<<g, 1024, D->lds.total_bytes, st>>>(D->sc, D->lds, ox, oy, oz, dx, dy, dz, tm, t, u, v, prim, n);
+                else k_trace_lds<false><<<g, 1024, D->lds.total_bytes, st>>>(D->sc, D->lds, ox, oy, oz, dx, dy, dz, tm, t, u, v, prim, n);
+            } else if (any_hit) k_trace<true><<<grid, LRT_BLOCK, 0, st>>>(D->sc, ox, oy, oz, dx, dy, dz, tm, t, u, v, prim, n);
             else k_trace<false><<<grid, LRT_BLOCK, 0, st>>>(D->sc, ox, oy, oz, dx, dy, dz, tm, t, u, v, prim, n);
         }
         HIP_CHECK(hipMemcpyAsync(hits->t, t, (size_t) n * 4, hipMemcpyDeviceToHost, st));

@@ -16,6 +16,7 @@ struct Hit { float t, u, v; uint32_t prim; };
 struct SI { bool valid; float t; V3 p, n; Frame sh; V2 uv; V3 dp_du, dp_dv, wi; uint32_t prim, shape; };
 
 // ------------------------------------------------------------- traversal
+DEV float slab_rcp(float x) { return fmin_(fmax_(__builtin_amdgcn_rcpf(x), -1e20f), 1e20f); }
 // Moeller-Trumbore on a pre-gathered triangle slot (include/mitsuba/render/mesh.h:506-527).
 // Ties are resolved towards the lower primitive index so that the result does
 // not depend on the traversal order.
@@ -47,43 +48,45 @@ DEV Hit trace(const DScene &sc, const Ray &r, int *__restrict__ stack /* &lds[th
         for (uint32_t i = 0; i < sc.root_leaf_count; ++i) test_tri(sc.tris, sc.root_leaf_first + i, o, d, r.maxt, best);
         return best;
     }
-    const float ix = 1.f / d.x, iy = 1.f / d.y, iz = 1.f / d.z;
-    int sp = 0, node = 0;
+    // "while-while" traversal (see trace_lds below for the rationale): descend to the next leaf with box tests only, then
+    // test the leaf's triangles.  Work items: inner node index (< 0x7fffffff), or 0x80000000 | first slot; a leaf
+    // ends at the slot whose e1.w is non-zero (bvh.cpp).
+    // The slab arithmetic only culls (padded boxes, hits decided by the exact triangle tests and the tie rule).
+    // reciprocals clamped to +-1e20: a direction component of (almost) zero must give (n - o) * huge = -+huge per plane, not
+    // inf - inf = NaN, so that rays parallel to a slab are kept or culled by the side of the origin (the padding decides ties)
+    const float ix = slab_rcp(d.x), iy = slab_rcp(d.y), iz = slab_rcp(d.z);
+    const float ox = -o.x * ix, oy = -o.y * iy, oz = -o.z * iz;
+    const uint32_t DONE = 0x7fffffffu;
+    int sp = 0; uint32_t cur = 0;
     for (;;) {
-        // ---- inner node: test both children
-        const float4 *nd = sc.nodes + 4 * (size_t) node;
-        float4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3];
-        float limit = fmin_(best.t, r.maxt);
-        float t0, t1, tmin0, tmax0, tmin1, tmax1;
-        t0 = (n0.x - o.x) * ix; t1 = (n0.y - o.x) * ix; tmin0 = fmax_(0.f, fmin_(t0, t1)); tmax0 = fmin_(limit, fmax_(t0, t1));
-        t0 = (n0.z - o.y) * iy; t1 = (n0.w - o.y) * iy; tmin0 = fmax_(tmin0, fmin_(t0, t1)); tmax0 = fmin_(tmax0, fmax_(t0, t1));
-        t0 = (n2.x - o.z) * iz; t1 = (n2.y - o.z) * iz; tmin0 = fmax_(tmin0, fmin_(t0, t1)); tmax0 = fmin_(tmax0, fmax_(t0, t1));
-        t0 = (n1.x - o.x) * ix; t1 = (n1.y - o.x) * ix; tmin1 = fmax_(0.f, fmin_(t0, t1)); tmax1 = fmin_(limit, fmax_(t0, t1));
-        t0 = (n1.z - o.y) * iy; t1 = (n1.w - o.y) * iy; tmin1 = fmax_(tmin1, fmin_(t0, t1)); tmax1 = fmin_(tmax1, fmax_(t0, t1));
-        t0 = (n2.z - o.z) * iz; t1 = (n2.w - o.z) * iz; tmin1 = fmax_(tmin1, fmin_(t0, t1)); tmax1 = fmin_(tmax1, fmax_(t0, t1));
-        bool h0 = tmin0 <= tmax0 * 1.0000005f + 1e-30f, h1 = tmin1 <= tmax1 * 1.0000005f + 1e-30f;
-        int r0 = (int) f2u(n3.x), r1 = (int) f2u(n3.y);
-        int next = 0x7fffffff;            // sentinel: nothing to descend into
-        if (h0 && h1) {
-            bool swap = tmin1 < tmin0;
-            int nearr = swap ? r1 : r0, farr = swap ? r0 : r1;
-            int nearc = swap ? (int) f2u(n3.w) : (int) f2u(n3.z), farc = swap ? (int) f2u(n3.z) : (int) f2u(n3.w);
-            // leaves are processed immediately, inner nodes are visited / pushed
-            if (farr < 0) { uint32_t first = (uint32_t) ~farr; for (int i = 0; i < farc; ++i) test_tri(sc.tris, first + i, o, d, r.maxt, best); }
-            if (nearr < 0) { uint32_t first = (uint32_t) ~nearr; for (int i = 0; i < nearc; ++i) test_tri(sc.tris, first + i, o, d, r.maxt, best); }
-            if (nearr >= 0) { next = nearr; if (farr >= 0) { stack[sp * LRT_BLOCK] = farr; ++sp; } }
-            else if (farr >= 0) next = farr;
-        } else if (h0 || h1) {
-            int rr = h0 ? r0 : r1, cc = h0 ? (int) f2u(n3.z) : (int) f2u(n3.w);
-            if (rr < 0) { uint32_t first = (uint32_t) ~rr; for (int i = 0; i < cc; ++i) test_tri(sc.tris, first + i, o, d, r.maxt, best); }
-            else next = rr;
+        while (cur < DONE) {
+            const float4 *nd = sc.nodes + 4 * (size_t) cur;
+            float4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3];
+            float limit = fmin_(best.t, r.maxt);
+            float ax0 = fma_(n0.x, ix, ox), ax1 = fma_(n0.y, ix, ox), ay0 = fma_(n0.z, iy, oy), ay1 = fma_(n0.w, iy, oy), az0 = fma_(n2.x, iz, oz), az1 = fma_(n2.y, iz, oz);
+            float bx0 = fma_(n1.x, ix, ox), bx1 = fma_(n1.y, ix, ox), by0 = fma_(n1.z, iy, oy), by1 = fma_(n1.w, iy, oy), bz0 = fma_(n2.z, iz, oz), bz1 = fma_(n2.w, iz, oz);
+            float tmin0 = fmax_(fmax_(fmin_(ax0, ax1), fmin_(ay0, ay1)), fmax_(fmin_(az0, az1), 0.f));
+            float tmax0 = fmin_(fmin_(fmax_(ax0, ax1), fmax_(ay0, ay1)), fmin_(fmax_(az0, az1), limit));
+            float tmin1 = fmax_(fmax_(fmin_(bx0, bx1), fmin_(by0, by1)), fmax_(fmin_(bz0, bz1), 0.f));
+            float tmax1 = fmin_(fmin_(fmax_(bx0, bx1), fmax_(by0, by1)), fmin_(fmax_(bz0, bz1), limit));
+            bool h0 = tmin0 <= tmax0 * 1.000002f + 1e-30f, h1 = tmin1 <= tmax1 * 1.000002f + 1e-30f;
+            int r0 = (int) f2u(n3.x), r1 = (int) f2u(n3.y);
+            uint32_t c0 = r0 < 0 ? (0x80000000u | (uint32_t) ~r0) : (uint32_t) r0;
+            uint32_t c1 = r1 < 0 ? (0x80000000u | (uint32_t) ~r1) : (uint32_t) r1;
+            if (h0 && h1) {
+                bool swap = tmin1 < tmin0;
+                stack[sp * LRT_BLOCK] = (int) (swap ? c0 : c1); ++sp;
+                cur = swap ? c1 : c0;
+            } else if (h0 || h1) cur = h0 ? c0 : c1;
+            else if (sp == 0) cur = DONE;
+            else { --sp; cur = (uint32_t) stack[sp * LRT_BLOCK]; }
         }
+        if (cur == DONE) break;
+        uint32_t slot = cur & 0x7fffffffu; bool last;
+        do { last = sc.tris[3 * slot + 1].w != 0.f; test_tri(sc.tris, slot, o, d, r.maxt, best); ++slot; } while (!last);
         if (ANY_HIT && best.prim != 0xffffffffu) return best;
-        if (next == 0x7fffffff) {
-            if (sp == 0) break;
-            --sp; next = stack[sp * LRT_BLOCK];
-        }
-        node = next;
+        if (sp == 0) break;
+        --sp; cur = (uint32_t) stack[sp * LRT_BLOCK];
     }
     return best;
 }
@@ -140,7 +143,9 @@ DEV Hit trace_lds(const LdsScene &L, const Ray &r, uint16_t *__restrict__ stack 
     // test their leaf triangles together; this keeps far more lanes busy than testing leaves where they are met.
     // Work items are 16-bit: inner node index (< 0x8000) or 0x8000 | first triangle slot; a leaf ends at the slot whose
     // index word carries the "last" flag (device.hip).
-    const float ix = __builtin_amdgcn_rcpf(d.x), iy = __builtin_amdgcn_rcpf(d.y), iz = __builtin_amdgcn_rcpf(d.z);
+    // reciprocals clamped to +-1e20: a direction component of (almost) zero must give (n - o) * huge = -+huge per plane, not
+    // inf - inf = NaN, so that rays parallel to a slab are kept or culled by the side of the origin (the padding decides ties)
+    const float ix = slab_rcp(d.x), iy = slab_rcp(d.y), iz = slab_rcp(d.z);
     const float ox = -o.x * ix, oy = -o.y * iy, oz = -o.z * iz;
     const uint32_t DONE = 0x10000u;
     int sp = 0; uint32_t cur = 0;

@@ -619,7 +619,8 @@ DEV void retire_and_compact_wave(const DScene &sc, const DRenderParams &rp, bool
 }
 
 template <int INTEGRATOR, int BLOCK, bool LDS_BVH, bool LD>
-__global__ void __launch_bounds__(BLOCK)
+// 4 waves per SIMD for every variant (128 VGPRs): one 1024-thread workgroup per CU, or four 256-thread ones
+__global__ void __launch_bounds__(BLOCK, 4)
 k_render(DScene sc, DRenderParams rp, DLdsInfo li, DPathStreams q0, DPathStreams q1, uint32_t P, DCounters *__restrict__ cnt,
          const uint32_t *__restrict__ pixel_list, uint64_t lane_begin, float *__restrict__ film, float *__restrict__ sample_out, uint64_t sample_base) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -854,6 +855,30 @@ k_trace(DScene sc, const float *ox, const float *oy, const float *oz, const floa
     Hit h = trace<ANY_HIT>(sc, r, s_stack + threadIdx.x);
     if (ANY_HIT) { t[i] = h.prim != 0xffffffffu ? 0.f : kInf; return; }
     t[i] = h.t; if (u) u[i] = h.u; if (v) v[i] = h.v; if (prim) prim[i] = h.prim;
+}
+
+// The same queries through the LDS-resident BVH image (1024 threads per workgroup, as in k_render)
+template <bool ANY_HIT>
+__global__ void __launch_bounds__(1024)
+k_trace_lds(DScene sc, DLdsInfo li, const float *ox, const float *oy, const float *oz, const float *dx, const float *dy, const float *dz, const float *tmax,
+            float *t, float *u, float *v, uint32_t *prim, uint32_t n) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const uint32_t tid = threadIdx.x;
+    {
+        const uint4 *src = li.blob; uint4 *dst = reinterpret_cast<uint4 *>(smem);
+        for (uint32_t k = tid; k < li.blob_bytes / 16u; k += 1024) dst[k] = src[k];
+    }
+    LdsScene L;
+    L.nodes = reinterpret_cast<const float4 *>(smem + li.nodes_off); L.verts = reinterpret_cast<const float4 *>(smem + li.verts_off);
+    L.tris = reinterpret_cast<const uint2 *>(smem + li.tris_off); L.slot_prim = li.slot_prim;
+    L.n_faces = sc.n_faces; L.root_is_leaf = (uint32_t) sc.root_is_leaf; L.root_first = sc.root_leaf_first; L.root_count = sc.root_leaf_count;
+    __syncthreads();
+    for (uint32_t i = blockIdx.x * 1024u + tid; i < n; i += gridDim.x * 1024u) {
+        Ray r; r.o = V3(ox[i], oy[i], oz[i]); r.d = V3(dx[i], dy[i], dz[i]); r.maxt = tmax[i];
+        Hit h = trace_lds<ANY_HIT, 1024>(L, r, reinterpret_cast<uint16_t *>(smem + li.stack_off) + tid);
+        if (ANY_HIT) { t[i] = h.prim != 0xffffffffu ? 0.f : kInf; continue; }
+        t[i] = h.t; if (u) u[i] = h.u; if (v) v[i] = h.v; if (prim) prim[i] = h.prim;
+    }
 }
 
 } // namespace lrt

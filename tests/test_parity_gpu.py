@@ -35,7 +35,10 @@ def center_lane(sc, spp, row_frac=0.5):
 
 
 # ------------------------------------------------------------------ ray queries
-def test_trace_staircase_closed_form(mi, orc):
+@pytest.mark.parametrize("lds", [True, False])
+def test_trace_staircase_closed_form(mi, orc, monkeypatch, lds):
+    """Axis-parallel rays (zero direction components) through both tracers: BVH image in LDS / BVH in global memory."""
+    if not lds: monkeypatch.setenv("LRT_NO_LDS_BVH", "1")
     v, f = _stairs(20)
     sc = mi.scene_from_buffers(v, f)
     o, d, yy = stairs_rays()
@@ -49,15 +52,19 @@ def test_trace_staircase_closed_form(mi, orc):
     assert (sc.trace(o, d, tmax, any_hit=True)[0] == 0).all()
 
 
-@pytest.mark.parametrize("which", ["cornell", "liver"])
-def test_trace_random_rays_bit_exact(mi, orc, cornell, liver_small, which):
+@pytest.mark.parametrize("which", ["cornell", "liver", "liver-global-bvh"])
+def test_trace_random_rays_bit_exact(mi, orc, cornell, liver_small, which, monkeypatch):
     rng = np.random.default_rng(11)
     n = 200000
     d = rng.normal(size=(n, 3)).astype(np.float32); d /= np.linalg.norm(d, axis=1, keepdims=True)
     if which == "cornell":
         sc, o = cornell, rng.uniform(-0.95, 0.95, (n, 3)).astype(np.float32)
     else:
-        sc = liver_small
+        if which == "liver-global-bvh":
+            monkeypatch.setenv("LRT_NO_LDS_BVH", "1")
+            sc = mi.load_file(LIVER_XML, integrator="volpath", spp=4, res_width=64, res_height=36)
+        else:
+            sc = liver_small
         o = (rng.uniform(-1, 1, (n, 3)) * [25, 20, 25] + [-43, -18, -43]).astype(np.float32)
     tmax = np.where(rng.random(n) < 0.5, np.finfo(np.float32).max, rng.uniform(0.1, 30, n)).astype(np.float32)
     g = sc.trace(o, d, tmax)
