@@ -324,6 +324,54 @@ def test_kernel_variants_bit_exact(mi, orc, monkeypatch, env):
     assert_lanes_equal(sc, orc.OrcScene(sc), center_lane(sc, 16), 1 << 14, spp=16)
 
 
+def _icosphere(levels):
+    p = (1 + 5 ** 0.5) / 2
+    v = [(-1, p, 0), (1, p, 0), (-1, -p, 0), (1, -p, 0), (0, -1, p), (0, 1, p), (0, -1, -p), (0, 1, -p), (p, 0, -1), (p, 0, 1), (-p, 0, -1), (-p, 0, 1)]
+    v = [np.array(x, np.float64) / np.linalg.norm(x) for x in v]
+    f = [(0, 11, 5), (0, 5, 1), (0, 1, 7), (0, 7, 10), (0, 10, 11), (1, 5, 9), (5, 11, 4), (11, 10, 2), (10, 7, 6), (7, 1, 8),
+         (3, 9, 4), (3, 4, 2), (3, 2, 6), (3, 6, 8), (3, 8, 9), (4, 9, 5), (2, 4, 11), (6, 2, 10), (8, 6, 7), (9, 8, 1)]
+    for _ in range(levels):
+        cache, nf = {}, []
+        def mid(a, b):
+            k = (min(a, b), max(a, b))
+            if k not in cache:
+                m = v[a] + v[b]; v.append(m / np.linalg.norm(m)); cache[k] = len(v) - 1
+            return cache[k]
+        for a, b, c in f:
+            ab, bc, ca = mid(a, b), mid(b, c), mid(c, a)
+            nf += [(a, ab, ca), (b, bc, ab), (c, ca, bc), (ab, bc, ca)]
+        f = nf
+    return np.array(v, np.float32), np.array(f, np.uint32)
+
+
+def test_large_mesh_in_global_memory(mi, orc, tmp_path):
+    """A mesh far too large for the LDS image (81 920 triangles, 40 962 vertices): BVH in global memory, 64^3 distance
+    field, fog inside a dielectric blob lit by a constant environment; lanes bit-exact, film within tolerance."""
+    v, f = _icosphere(6)
+    v = v * (1 + 0.15 * np.sin(5 * v[:, :1]) * np.cos(4 * v[:, 1:2])).astype(np.float32) * np.float32(2.0)
+    with open(tmp_path / "blob.obj", "w") as fh:
+        fh.write("".join(f"v {a:.7g} {b:.7g} {c:.7g}\n" for a, b, c in v) + "".join(f"f {a + 1} {b + 1} {c + 1}\n" for a, b, c in f))
+    xml = f"""<scene version="3.0.0">
+  <integrator type="volpath"><integer name="max_depth" value="10"/></integrator>
+  <medium type="homogeneous" id="fog"><rgb name="sigma_t" value="2.0, 1.5, 1.0"/><rgb name="albedo" value="0.9, 0.8, 0.7"/><phase type="hg"><float name="g" value="0.3"/></phase></medium>
+  <sensor type="perspective"><float name="fov" value="40"/>
+    <transform name="to_world"><lookat origin="0, 1, 7" target="0, 0, 0" up="0, 1, 0"/></transform>
+    <sampler type="independent"><integer name="sample_count" value="16"/></sampler>
+    <film type="hdrfilm"><integer name="width" value="96"/><integer name="height" value="96"/><rfilter type="box"/></film>
+  </sensor>
+  <shape type="obj"><string name="filename" value="blob.obj"/><bsdf type="dielectric"/><ref name="interior" id="fog"/></shape>
+  <emitter type="constant"><rgb name="radiance" value="1.0, 0.9, 0.8"/></emitter>
+</scene>"""
+    sc = mi.load_string(xml, base_dir=tmp_path)
+    assert sc.desc.n_faces == 81920
+    o = orc.OrcScene(sc)
+    assert_lanes_equal(sc, o, center_lane(sc, 16, 0.45), 1 << 15)
+    st = sc.stats()
+    assert st["n_records"] > 0 and st["n_records"] < st["n_iter"]
+    img, raw = sc.render(return_raw=True)
+    assert film_close(raw, o.render(return_raw=True)[1]).all()
+
+
 def test_lookahead_is_invisible_in_statistics(mi, monkeypatch):
     """The look-ahead retires trips early and skips ray queries, but n_iter / n_shadow count what the reference's loop does."""
     a = mi.load_file(LIVER_XML, integrator="volpath", spp=8, res_width=320, res_height=180)
