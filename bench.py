@@ -118,7 +118,7 @@ def main():
             pass
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                "kernel": "lrt::k_render<%d, 1024, true>" % (0 if a.integrator == "path" else 1),
+                "kernel": "lrt::k_render<%d, 1024, true, false>" % (0 if a.integrator == "path" else 1),
                 "launches_per_step": launches / a.steps, "avg_launch_ms": kern_ms / max(launches, 1),
                 "alg_bytes_per_launch": alg_bytes / max(launches, 1), "iterations_per_sample": iters / (n_rank * a.steps),
                 "records_per_sample": records / (n_rank * a.steps)}
