@@ -43,7 +43,7 @@ struct DeviceScene {
     uint32_t *pixel_list = nullptr; uint32_t pixel_list_rank = 0xffffffffu, pixel_list_count = 0, n_owned_pixels = 0;
     std::vector<hipEvent_t> ev_pool;
     std::vector<DMedium> h_media; DMedium *d_media = nullptr;
-    DLdsInfo lds{}; bool use_lds = false; int n_cus = 256; int lds_block = 1024;
+    DLdsInfo lds{}; bool use_lds = false; int n_cus = 256;
 
     template <typename T> T *track(T *p) { allocs.push_back((void *) p); return p; }
     ~DeviceScene() {
@@ -180,8 +180,7 @@ DeviceScene *device_scene_create(const lrt_scene_desc &d, int device) {
         hipDeviceProp_t prop; HIP_CHECK(hipGetDeviceProperties(&prop, device)); D->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         const size_t n_nodes = bvh.nodes.size() / 16, n_slots = bvh.tris.size() / 12, n_verts = d.n_vertices;
         const size_t nodes_b = n_nodes * 64, verts_b = (n_verts * 16 + 15) & ~size_t(15), tris_b = (n_slots * 8 + 15) & ~size_t(15);
-        D->lds_block = 1024;
-        const size_t stack_b = (size_t) 2 * LRT_LDS_STACK * D->lds_block, total = nodes_b + verts_b + tris_b + stack_b;
+        const size_t stack_b = (size_t) 2 * LRT_LDS_STACK * 1024, total = nodes_b + verts_b + tris_b + stack_b;
         const size_t lds_limit = std::min<size_t>((size_t) prop.sharedMemPerBlock ? 160 * 1024 : 64 * 1024, 160 * 1024) - 512;
         if (d.n_faces > 0 && n_verts <= 65535 && n_nodes <= 32767 && n_slots <= 32767 && bvh.max_depth < LRT_LDS_STACK && total <= lds_limit && !getenv("LRT_NO_LDS_BVH")) {
             std::vector<unsigned char> blob(nodes_b + verts_b + tris_b, 0);
@@ -426,7 +425,7 @@ static DRenderParams make_params(const lrt_scene_desc &d, const ResolvedOpts &O,
     return rp;
 }
 
-struct LaunchLog { std::vector<std::pair<hipEvent_t, hipEvent_t>> launches; std::vector<uint32_t> sizes; std::vector<std::array<uint32_t, 3>> regions; unsigned long long n_records = 0; size_t ev = 0; uint64_t n_iter = 0; };
+struct LaunchLog { std::vector<std::pair<hipEvent_t, hipEvent_t>> launches; std::vector<uint32_t> sizes; unsigned long long n_records = 0; size_t ev = 0; uint64_t n_iter = 0; };
 
 static void finish_stats(DeviceScene *D, LaunchLog &log, hipEvent_t e_begin, hipEvent_t e_end, uint64_t n_lanes, lrt_render_stats &stats) {
     hipStream_t st = D->stream;
@@ -440,9 +439,7 @@ static void finish_stats(DeviceScene *D, LaunchLog &log, hipEvent_t e_begin, hip
     for (size_t i = 0; i < log.launches.size(); ++i) {
         HIP_CHECK(hipEventElapsedTime(&ms, log.launches[i].first, log.launches[i].second)); ksum += ms;
         if (getenv("LRT_DEBUG_LAUNCH") && i < 40) {
-            fprintf(stderr, "[lrt] launch %zu: n=%u %.3f ms (%.2f Gpath-iter/s)", i, log.sizes[i], ms, log.sizes[i] / ms * 1e-6);
-            if (i < log.regions.size()) fprintf(stderr, "  proven-free %u  query %u  surface %u", log.regions[i][0], log.regions[i][1], log.regions[i][2]);
-            fprintf(stderr, "\n");
+            fprintf(stderr, "[lrt] launch %zu: %.3f ms\n", i, ms);
         }
     }
     stats.kernel_ms = ksum;
@@ -460,7 +457,7 @@ static PoolGeometry pool_geometry(DeviceScene *D, uint64_t n_lanes) {
     g.n_wg = D->use_lds ? (uint32_t) D->n_cus : 4u * (uint32_t) D->n_cus;
     const uint32_t pool_max = getenv("LRT_POOL") ? std::max(64, atoi(getenv("LRT_POOL"))) : (D->use_lds ? 32768u : 8192u);
     g.P = (uint32_t) std::min<uint64_t>(pool_max, std::max<uint64_t>(64, ((n_lanes + g.n_wg - 1) / g.n_wg + 63) / 64 * 64));
-    g.block = D->use_lds ? (uint32_t) D->lds_block : (uint32_t) LRT_BLOCK;
+    g.block = D->use_lds ? 1024u : (uint32_t) LRT_BLOCK;
     g.smem = D->use_lds ? D->lds.total_bytes : (size_t) LRT_STACK * LRT_BLOCK * sizeof(int);
     return g;
 }

@@ -133,8 +133,7 @@ struct DPathStreams {
 #define PF_NOHIT        (1u << 28)     // look-ahead proved that the next free-flight segment reaches no surface
 
 struct DCounters {             // device-resident queue / statistics words
-    uint32_t n_in, n_out;      // PRB wavefront (kernels_prb.h): survivors of the current launch
-    uint32_t tile, pad;
+    uint32_t pad[4];
     unsigned long long n_shadow;   // NEE ray queries actually needed
     unsigned long long n_iter;     // loop trips (render kernel)
     unsigned long long next_lane;  // global camera-lane ticket (render kernel)

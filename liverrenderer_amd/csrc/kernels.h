@@ -1,16 +1,15 @@
-// gfx950 wavefront kernels of the hip_ad_rgb hot path (included by device.hip).
+// gfx950 kernels of the hip_ad_rgb hot path (included by device.hip).
 //
-//   k_raygen   SamplingIntegrator::render lane set-up + render_sample prologue
-//              (src/render/integrator.cpp:308-338,449-486; src/render/sampler.cpp:129-148;
-//               src/sensors/perspective.cpp:239-279) -> path-state streams
-//   k_iterate  one trip of the integrator's dr::while_loop for every live path
-//              (src/integrators/volpath.cpp:170-391 incl. sample_emitter :400-554,
-//               src/integrators/path.cpp:194-338), reading the in-queue streams,
-//              compacting survivors into the out-queue with __ballot/popcount and
-//              one queue atomic per workgroup, and splatting finished paths into
-//              the film (src/render/imageblock.cpp:174-232,431-500)
-//   k_develop  HDRFilm::develop (src/films/hdrfilm.cpp:306-410)
-//   k_trace    SoA ray queries (test hook, src/render/scene_native.inl:135-202)
+//   k_render          the whole sample loop of one lrt_render in ONE persistent launch: camera-lane generation
+//                     (src/render/integrator.cpp:308-338,449-486; src/render/sampler.cpp:97-148;
+//                      src/sensors/perspective.cpp:239-279), one trip of the integrator's dr::while_loop per tile visit
+//                     (src/integrators/volpath.cpp:170-391 incl. sample_emitter :400-554, src/integrators/path.cpp:194-338),
+//                     survivor compaction with __ballot/popcount into per-workgroup queues, film splat
+//                     (src/render/imageblock.cpp:174-232,431-500)
+//   k_splat_lanes     film accumulation pass for reconstruction filters wider than a pixel
+//   k_build_dist_grid conservative distance field (scene upload)
+//   k_develop         HDRFilm::develop (src/films/hdrfilm.cpp:306-410)
+//   k_trace[_lds]     SoA ray queries (test hook, src/render/scene_native.inl:135-202)
 #pragma once
 #include "dshade.h"
 
