@@ -36,6 +36,7 @@ def parse():
     p.add_argument("--scene", default=os.path.join(ROOT, "scenes", "Liver-SingleMesh", "mitsuba3", "scene.xml"))
     p.add_argument("--integrator", default="volpath")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--backend", default="nccl", help="process-group backend; gloo allows a multi-rank rehearsal on a single GPU")
     p.add_argument("--cpu-spp", type=int, default=0, help="spp of the bounded CPU-baseline sample (0: calibrate to ~15 s)")
     return p.parse_args()
 
@@ -54,12 +55,14 @@ def main():
             raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N ...")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the hip_ad_rgb back-end has no CPU fallback)")
+    local_rank %= max(torch.cuda.device_count(), 1)            # several ranks share a GPU only in a gloo rehearsal
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if a.backend == "nccl": dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else: dist.init_process_group(a.backend)
 
     scene = mi.load_file(a.scene, integrator=a.integrator, spp=a.spp, res_width=a.width, res_height=a.height)
     h, w, _ = scene.film_shape()
