@@ -292,6 +292,54 @@ def test_white_furnace_medium(mi, orc):
     assert img.mean() == pytest.approx(1.0, abs=0.015)
 
 
+def _slab_xml(sigma_t, albedo, integrator, spp, max_depth=-1, radiance="1, 1, 1", phase='<phase type="isotropic"/>'):
+    # camera on the -z side looking along +z through a cube [-1,1]^3 filled with the medium; null boundary
+    return f"""<scene version="3.0.0">
+      <integrator type="{integrator}"><integer name="max_depth" value="{max_depth}"/></integrator>
+      <sensor type="perspective"><float name="fov" value="2"/>
+        <transform name="to_world"><lookat origin="0, 0, -20" target="0, 0, 0" up="0, 1, 0"/></transform>
+        <sampler type="independent"><integer name="sample_count" value="{spp}"/></sampler>
+        <film type="hdrfilm"><integer name="width" value="8"/><integer name="height" value="8"/><rfilter type="box"/></film>
+      </sensor>
+      <medium type="homogeneous" id="fog"><rgb name="sigma_t" value="{sigma_t}"/><rgb name="albedo" value="{albedo}"/>{phase}</medium>
+      <shape type="cube"><bsdf type="null"/><ref name="interior" id="fog"/></shape>
+      <emitter type="constant"><rgb name="radiance" value="{radiance}"/></emitter>
+    </scene>"""
+
+
+@pytest.mark.parametrize("integrator", ["volpath", "prbvolpath"])
+def test_beer_lambert_transmittance(mi, orc, integrator):
+    """Purely absorbing medium (albedo 0) of thickness 2 in front of a radiance-1 environment: the pixel value is
+    exp(-2 sigma_t) per channel, the analytic known answer for free-flight sampling + spectral weights
+    (volpath.cpp:219-232, medium.cpp:92-104)."""
+    sig = np.array([0.3, 0.8, 1.4])
+    sc = mi.load_string(_slab_xml("0.3, 0.8, 1.4", "0, 0, 0", integrator, 4096))
+    img = orc.OrcScene(sc).render().astype(np.float64)[..., :3]
+    expect = np.exp(-2 * sig)
+    assert np.allclose(img.mean((0, 1)), expect, rtol=0.02), (img.mean((0, 1)), expect)
+
+
+def test_single_scattering_closed_form(mi, orc):
+    """max_depth 2 in a thin-ish isotropic medium lit by a constant environment L: unscattered light exp(-tau) L plus one
+    scattering event.  For a ray along the slab axis the single-scattered radiance is
+    a * int_0^d sigma e^(-sigma s) * (1/4pi) int_{S^2} e^(-sigma * l(s, w)) dw ds * L, evaluated here by quadrature over the cube."""
+    sigma, a, L = 0.6, 0.9, 1.0
+    sc = mi.load_string(_slab_xml(f"{sigma}, {sigma}, {sigma}", f"{a}, {a}, {a}", "volpath", 8192, max_depth=2))
+    img = orc.OrcScene(sc).render().astype(np.float64)[..., :3].mean()
+    rng = np.random.default_rng(0)
+    n = 400000
+    s = rng.random(n) * 2.0                                   # depth of the scattering point on the axis (entry z = -1)
+    z = rng.random(n) * 2 - 1; ph = rng.random(n) * 2 * np.pi
+    w = np.stack([np.sqrt(1 - z * z) * np.cos(ph), np.sqrt(1 - z * z) * np.sin(ph), z], 1)
+    p = np.stack([np.zeros(n), np.zeros(n), -1 + s], 1)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        t = np.where(w > 0, (1 - p) / w, (-1 - p) / w)        # exit distance from the cube along w
+    l = np.nanmin(np.where(np.isfinite(t), t, np.inf), axis=1)
+    single = a * np.mean(2.0 * sigma * np.exp(-sigma * s) * np.exp(-sigma * l)) * L
+    expect = np.exp(-2 * sigma) * L + single
+    assert img == pytest.approx(expect, rel=0.015), (img, expect)
+
+
 # ---- PRB adjoint: gradients vs finite differences (src/integrators/tests/test_ad_integrators.py:1459-1500) ----
 def prb_scene_xml(boundary, env, sample_emitters="true", g=0.4, rf="box", res=8):
     return f"""<scene version="3.0.0">
