@@ -540,7 +540,7 @@ void device_render(DeviceScene *D, const lrt_scene_desc &d, const lrt_render_opt
             lrt_render_stats st1{};
             run_wavefront(D, d, O, base, n, pixel_list, nullptr, reinterpret_cast<float *>(D->L_buf), st1);
             DRenderParams rp = make_params(d, O, n);
-            k_splat_lanes<<<(uint32_t) ((n + LRT_BLOCK - 1) / LRT_BLOCK), LRT_BLOCK, 0, D->stream>>>(D->sc, rp, D->L_buf, pixel_list, base, n, film);
+            k_splat_lanes<false><<<(uint32_t) ((n + LRT_BLOCK - 1) / LRT_BLOCK), LRT_BLOCK, 0, D->stream>>>(D->sc, rp, D->L_buf, pixel_list, base, n, film);
             HIP_CHECK(hipGetLastError());
             total.n_samples += st1.n_samples; total.n_iter += st1.n_iter; total.n_shadow += st1.n_shadow; total.n_launches += st1.n_launches;
             total.n_records += st1.n_records; total.kernel_ms += st1.kernel_ms; total.total_ms += st1.total_ms;
@@ -653,8 +653,13 @@ void device_render_backward(DeviceScene *D, const lrt_scene_desc &d, const lrt_r
     if (F.rfilter != LRT_RFILTER_BOX) {
         if (D->wfilm_floats < np) { HIP_CHECK(hipMalloc((void **) &D->wfilm, np * 4)); D->track(D->wfilm); D->wfilm_floats = np; }
         HIP_CHECK(hipMemsetAsync(D->wfilm, 0, np * 4, st));
-        uint64_t all = (uint64_t) np * O.spp;             // every lane of the image, also those of other ranks' tiles
-        k_weight_film<<<(uint32_t) ((all + LRT_BLOCK - 1) / LRT_BLOCK), LRT_BLOCK, 0, st>>>(D->sc, rp, D->wfilm, all);
+        // sum of reconstruction-filter weights per pixel over every lane of the image (also those of other ranks' tiles)
+        uint64_t all = (uint64_t) np * O.spp;
+        DRenderParams rw = make_params(d, O, all);
+        for (uint64_t base = 0; base < all; base += (1ull << 30)) {
+            const uint64_t n = std::min<uint64_t>(1ull << 30, all - base);
+            k_splat_lanes<true><<<(uint32_t) ((n + LRT_BLOCK - 1) / LRT_BLOCK), LRT_BLOCK, 0, st>>>(D->sc, rw, nullptr, nullptr, base, n, D->wfilm);
+        }
     }
     HIP_CHECK(hipMemsetAsync(D->d_grads, 0, 7 * sizeof(double), st));
     HIP_CHECK(hipMemsetAsync(D->counters, 0, sizeof(DCounters), st));

@@ -779,6 +779,9 @@ k_build_dist_grid(const float4 *__restrict__ tris, uint32_t n_slots, DDistGrid g
 // wave belong to one or two pixels: the filter footprint of a group of lanes with the same footprint origin is reduced
 // inside the wave (one butterfly per cell and channel) and lane c issues the atomics of cell c.  Compared with splatting
 // where paths happen to retire this divides the float atomics by the group size (up to 64).
+// WEIGHTS_ONLY: accumulate just the filter weights into a one-channel film (the PRB adjoint's normalisation image,
+// common.py:730-746); lane_L is not read.
+template <bool WEIGHTS_ONLY>
 __global__ void __launch_bounds__(LRT_BLOCK)
 k_splat_lanes(DScene sc, DRenderParams rp, const float4 *__restrict__ lane_L, const uint32_t *__restrict__ pixel_list, uint64_t slot_base, uint64_t n,
               float *__restrict__ film) {
@@ -792,9 +795,11 @@ k_splat_lanes(DScene sc, DRenderParams rp, const float4 *__restrict__ lane_L, co
         uint32_t lane;
         if (pixel_list) { uint32_t pj = (uint32_t) (j / rp.spp); lane = pixel_list[pj] * rp.spp + (uint32_t) (j - (uint64_t) pj * rp.spp); }
         else lane = (uint32_t) j;
-        const float4 v = lane_L[i];
-        L = V3(v.x, v.y, v.z); alpha = v.w;
-        if (rp.integrator == LRT_INTEGRATOR_PATH && alpha == 0.f) L = V3(0.f);         // path.cpp:342-345
+        if (!WEIGHTS_ONLY) {
+            const float4 v = lane_L[i];
+            L = V3(v.x, v.y, v.z); alpha = v.w;
+            if (rp.integrator == LRT_INTEGRATOR_PATH && alpha == 0.f) L = V3(0.f);     // path.cpp:342-345
+        }
         int px, py; lane_to_pixel(sc, rp, lane, &px, &py);
         float jx, jy; lane_jitter(rp, lane, jx, jy);
         float spx = (float) px + jx, spy = (float) py + jy;
@@ -816,7 +821,8 @@ k_splat_lanes(DScene sc, DRenderParams rp, const float4 *__restrict__ lane_L, co
                 const float w = mine ? wy * rfilter_eval(F, relx + (float) xs) : 0.f;
                 float r = L.x * w, g = L.y * w, b = L.z * w, a = alpha * w, ww = w;
                 for (int off = 32; off > 0; off >>= 1) {
-                    r += __shfl_xor(r, off); g += __shfl_xor(g, off); b += __shfl_xor(b, off); a += __shfl_xor(a, off); ww += __shfl_xor(ww, off);
+                    if (!WEIGHTS_ONLY) { r += __shfl_xor(r, off); g += __shfl_xor(g, off); b += __shfl_xor(b, off); a += __shfl_xor(a, off); }
+                    ww += __shfl_xor(ww, off);
                 }
                 if ((int) me == ys * count + xs) { tr = r; tg = g; tb = b; ta = a; tw = ww; }
             }
@@ -825,9 +831,12 @@ k_splat_lanes(DScene sc, DRenderParams rp, const float4 *__restrict__ lane_L, co
             const int ys = (int) me / count, xs = (int) me - ys * count;
             const int x = gx - F.crop_offset_x + xs, y = gy - F.crop_offset_y + ys;
             if (x >= 0 && x < F.width && y >= 0 && y < F.height) {
-                float *p = film + ((size_t) y * F.width + x) * C;
-                atomicAdd(p + 0, tr); atomicAdd(p + 1, tg); atomicAdd(p + 2, tb);
-                if (F.has_alpha) { atomicAdd(p + 3, ta); atomicAdd(p + 4, tw); } else atomicAdd(p + 3, tw);
+                if (WEIGHTS_ONLY) atomicAdd(film + (size_t) y * F.width + x, tw);
+                else {
+                    float *p = film + ((size_t) y * F.width + x) * C;
+                    atomicAdd(p + 0, tr); atomicAdd(p + 1, tg); atomicAdd(p + 2, tb);
+                    if (F.has_alpha) { atomicAdd(p + 3, ta); atomicAdd(p + 4, tw); } else atomicAdd(p + 3, tw);
+                }
             }
         }
         todo &= ~__ballot(mine);

@@ -237,29 +237,6 @@ DEV void lane_sample_pos(const DScene &sc, const DRenderParams &rp, uint32_t lan
     *spx = (float) *px + jx; *spy = (float) *py + jy;
 }
 
-// Sum of reconstruction-filter weights per pixel over ALL lanes of the render (non-box filters).
-__global__ void __launch_bounds__(LRT_BLOCK)
-k_weight_film(DScene sc, DRenderParams rp, float *__restrict__ wfilm, uint64_t n_lanes) {
-    uint64_t i = (uint64_t) blockIdx.x * LRT_BLOCK + threadIdx.x;
-    if (i >= n_lanes) return;
-    const DFilm &F = sc.film;
-    float spx, spy; int px, py; lane_sample_pos(sc, rp, (uint32_t) i, &spx, &spy, &px, &py);
-    int n = F.fn, count = F.fcount;
-    int pix = (int) __builtin_floorf(spx) - n, piy = (int) __builtin_floorf(spy) - n;
-    float relx = (float) pix + .5f - spx, rely = (float) piy + .5f - spy;
-    for (int ys = 0; ys < count; ++ys) {
-        int y = piy - F.crop_offset_y + ys;
-        if (y < 0 || y >= F.height) continue;
-        float wy = rfilter_eval(F, rely + (float) ys);
-        for (int xs = 0; xs < count; ++xs) {
-            int x = pix - F.crop_offset_x + xs;
-            if (x < 0 || x >= F.width) continue;
-            float w = wy * rfilter_eval(F, relx + (float) xs);
-            if (w != 0.f) atomicAdd(wfilm + (size_t) y * F.width + x, w);
-        }
-    }
-}
-
 // delta_L of a lane: gradient of sum(image * grad_image) w.r.t. the lane's radiance through splat + develop
 // (common.py:730-746).  Box filter: grad[pixel] / W[pixel].
 DEV V3 lane_delta_L(const DScene &sc, const DRenderParams &rp, uint32_t lane, const float *__restrict__ grad_image, const float *__restrict__ wfilm) {
