@@ -82,6 +82,7 @@ template <bool ADJOINT, typename SMP, typename TR>
 DEV bool prb_iteration(const DScene &sc, const DRenderParams &rp, PathState &s, SMP &rng, const TR &tr, uint32_t &n_shadow,
                        V3 delta_L, PrbGrads &G) {
     uint32_t depth = s.flags & PF_DEPTH_MASK;
+    const bool proven_empty = (s.flags & PF_NOHIT) != 0;               // look-ahead of the previous trip, see below
     int medium = (int) ((s.flags & PF_MEDIUM_MASK) >> PF_MEDIUM_SHIFT) - 1;
     const uint32_t channel = (s.flags >> PF_CHANNEL_SHIFT) & 3u;
     bool specular_chain = (s.flags & PF_SPECULAR) != 0, valid_ray = (s.flags & PF_VALID) != 0;
@@ -110,7 +111,7 @@ DEV bool prb_iteration(const DScene &sc, const DRenderParams &rp, PathState &s, 
         const DMedium M = sc.media[medium];
         mei = medium_sample_interaction(M, ray, rng.next(), channel);
         if (mei.valid()) ray.maxt = mei.t;
-        { Hit h = tr.closest(ray); si = compute_si(sc, ray, h); }
+        if (!proven_empty) { Hit h = tr.closest(ray); si = compute_si(sc, ray, h); }
         if (si.t < mei.t) mei.t = kInf;
         seg_t = fmin_(mei.t, si.t) - mei.mint;
         V3 tr(m_exp(-seg_t * mei.combined.x), m_exp(-seg_t * mei.combined.y), m_exp(-seg_t * mei.combined.z));
@@ -226,7 +227,23 @@ DEV bool prb_iteration(const DScene &sc, const DRenderParams &rp, PathState &s, 
         }
     }
     active = active && (active_surface || active_medium);
+    // Look-ahead (as in volpath_iteration): replay the next trip's Russian-roulette and free-flight draws on a copy of the
+    // sampler; when the distance field proves that the segment reaches no surface, the path is queued apart and its next
+    // trip runs no ray query.  Exact: same draws, same functions, conservative proof.
+    uint32_t nohit = 0;
+    if (active && medium >= 0 && sc.grid.enabled) {
+        SMP pk = rng;
+        bool a2 = any_nonzero(throughput);
+        float q2 = fmin_(max3(throughput) * sqr(eta), 0.99f);
+        if (a2) { float u = pk.next(); a2 = (u < q2) || !(depth > (uint32_t) rp.rr_depth); }
+        if (a2) {
+            const DMedium M = sc.media[medium];
+            MI m2 = medium_sample_interaction(M, ray, pk.next(), channel);
+            if (m2.valid() && segment_proven_empty(sc.grid, ray.o, ray.d, m2.t)) nohit = PF_NOHIT;
+        }
+    }
     commit();
+    s.flags |= nohit;
     return active;
 }
 
@@ -269,8 +286,8 @@ DEV V3 lane_delta_L(const DScene &sc, const DRenderParams &rp, uint32_t lane, co
     return dL;
 }
 
-// PRB passes on the persistent render kernel of kernels.h (same rounds, pools and tiles; two queue regions: in-medium
-// paths from the front, the others from the back; one extra float4 stream carries delta_L and the lane's slot).
+// PRB passes on the persistent render kernel of kernels.h (same rounds, pools, tiles, queue regions and look-ahead;
+// one extra float4 stream carries delta_L and the lane's slot).
 // ADJOINT == false: primal pass; finished lanes store L into L_buf[slot] (slot = index of the lane in this launch), or
 //                   splat into the film / sample_out when L_buf is null (lrt_render with integrator prbvolpath).
 // ADJOINT == true : replay; finished lanes only retire; the parameter gradients of a tile are summed inside the wave,
@@ -283,7 +300,7 @@ k_render_prb(DScene sc, DRenderParams rp, DLdsInfo li, DPathStreams q0, DPathStr
              float4 *__restrict__ L_buf, const float *__restrict__ grad_image, const float *__restrict__ wfilm, double *__restrict__ grads,
              float *__restrict__ film, float *__restrict__ sample_out, uint64_t sample_base) {
     extern __shared__ __align__(16) unsigned char smem[];
-    __shared__ uint32_t s_in[2], s_out[2], s_ticket, s_fresh;
+    __shared__ uint32_t s_in[3], s_out[3], s_ticket, s_fresh;
     __shared__ unsigned long long s_fresh_base;
     __shared__ double s_grad[7];
     const uint32_t tid = threadIdx.x, lane_in_wave = tid & 63u;
@@ -300,26 +317,28 @@ k_render_prb(DScene sc, DRenderParams rp, DLdsInfo li, DPathStreams q0, DPathStr
     const size_t pool = (size_t) blockIdx.x * 2u * P;
     DPathStreams qin = offset_streams(q0, pool), qout = offset_streams(q1, pool);
     float4 *dlin = dl0 + pool, *dlout = dl1 + pool;
-    if (tid == 0) { s_in[0] = s_in[1] = 0; }
+    if (tid == 0) { s_in[0] = s_in[1] = s_in[2] = 0; }
     if (tid < 7) s_grad[tid] = 0.0;
     bool lanes_left = true;                                   // thread 0
     uint32_t n_shadow = 0, n_trips = 0, n_loaded = 0;
     for (;;) {
         if (tid == 0) {
-            const uint32_t want = P - (s_in[0] + s_in[1]);
+            const uint32_t want = P - (s_in[0] + s_in[1] + s_in[2]);
             uint32_t got = 0; unsigned long long base = 0;
             if (want && lanes_left) {
                 base = atomicAdd(&cnt->next_lane, (unsigned long long) want);
                 if (base < rp.n_lanes) got = (uint32_t) (rp.n_lanes - base < (unsigned long long) want ? rp.n_lanes - base : (unsigned long long) want);
                 lanes_left = base + want < rp.n_lanes;
             }
-            s_fresh = got; s_fresh_base = base; s_ticket = 0; s_out[0] = s_out[1] = 0;
+            s_fresh = got; s_fresh_base = base; s_ticket = 0; s_out[0] = s_out[1] = s_out[2] = 0;
         }
         __syncthreads();
-        const uint32_t n_m = s_in[0], n_s = s_in[1], fresh = s_fresh;
+        // queue regions as in k_render: A [0, n_a) proven-free in-medium paths, C [P, P + n_c) in-medium paths that need their
+        // ray query, B 2P-1-j paths outside media
+        const uint32_t n_a = s_in[0], n_c = s_in[1], n_s = s_in[2], fresh = s_fresh;
         const unsigned long long fresh_base = s_fresh_base;
-        if (n_m + n_s + fresh == 0) break;
-        const uint32_t tm = (n_m + 63u) >> 6, ts = (n_s + 63u) >> 6, tf = (fresh + 63u) >> 6;
+        if (n_a + n_c + n_s + fresh == 0) break;
+        const uint32_t ta = (n_a + 63u) >> 6, tc = (n_c + 63u) >> 6, ts = (n_s + 63u) >> 6, tf = (fresh + 63u) >> 6, tm = ta + tc;
         for (;;) {
             uint32_t t = 0;
             if (lane_in_wave == 0) t = atomicAdd(&s_ticket, 1u);
@@ -330,7 +349,8 @@ k_render_prb(DScene sc, DRenderParams rp, DLdsInfo li, DPathStreams q0, DPathStr
             float4 dl = make_float4(0.f, 0.f, 0.f, 0.f);
             if (t < tm + ts) {
                 uint32_t i;
-                if (t < tm) { i = (t << 6) + lane_in_wave; had_path = i < n_m; }
+                if (t < ta) { i = (t << 6) + lane_in_wave; had_path = i < n_a; }
+                else if (t < tm) { i = ((t - ta) << 6) + lane_in_wave; had_path = i < n_c; i += P; }
                 else { i = ((t - tm) << 6) + lane_in_wave; had_path = i < n_s; i = 2u * P - 1u - i; }
                 if (had_path) { load_state(qin, i, s); dl = dlin[i]; n_loaded += 1; }
             } else {
@@ -365,20 +385,20 @@ k_render_prb(DScene sc, DRenderParams rp, DLdsInfo li, DPathStreams q0, DPathStr
                     if (lane_in_wave == 0 && v != 0.f) atomicAdd(&s_grad[k], (double) v);
                 }
             }
-            // compaction: in-medium survivors to the front, the others to the back
-            const bool in_medium = (s.flags & PF_MEDIUM_MASK) != 0;
-            const unsigned long long mm = __ballot(alive && in_medium), ms = __ballot(alive && !in_medium);
+            // compaction into the three regions
+            const int region = !(s.flags & PF_MEDIUM_MASK) ? 2 : ((s.flags & PF_NOHIT) ? 0 : 1);
+            const unsigned long long m0 = __ballot(alive && region == 0), m1 = __ballot(alive && region == 1), m2 = __ballot(alive && region == 2);
             uint32_t base = 0;
-            if (lane_in_wave < 2) { const uint32_t c = (uint32_t) __popcll(lane_in_wave == 0 ? mm : ms); if (c) base = atomicAdd(&s_out[lane_in_wave], c); }
-            const uint32_t b = __shfl(base, in_medium ? 0 : 1);
+            if (lane_in_wave < 3) { const uint32_t c = (uint32_t) __popcll(lane_in_wave == 0 ? m0 : (lane_in_wave == 1 ? m1 : m2)); if (c) base = atomicAdd(&s_out[lane_in_wave], c); }
+            const uint32_t b = __shfl(base, region);
             if (alive) {
-                const uint32_t slot = b + (uint32_t) __popcll((in_medium ? mm : ms) & ((1ull << lane_in_wave) - 1ull));
-                const uint32_t rec = in_medium ? slot : 2u * P - 1u - slot;
+                const uint32_t slot = b + (uint32_t) __popcll((region == 0 ? m0 : (region == 1 ? m1 : m2)) & ((1ull << lane_in_wave) - 1ull));
+                const uint32_t rec = region == 0 ? slot : (region == 1 ? P + slot : 2u * P - 1u - slot);
                 store_state(qout, rec, s); dlout[rec] = dl;
             }
         }
         __syncthreads();
-        if (tid == 0) { s_in[0] = s_out[0]; s_in[1] = s_out[1]; }
+        if (tid == 0) { s_in[0] = s_out[0]; s_in[1] = s_out[1]; s_in[2] = s_out[2]; }
         const DPathStreams tmp = qin; qin = qout; qout = tmp;
         float4 *tdl = dlin; dlin = dlout; dlout = tdl;
     }
