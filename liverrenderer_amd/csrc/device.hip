@@ -46,6 +46,11 @@ struct DeviceScene {
     DLdsInfo lds{}; bool use_lds = false; int n_cus = 256;
 
     template <typename T> T *track(T *p) { allocs.push_back((void *) p); return p; }
+    void release(void *p) {                // free one tracked allocation now (a workspace that is being replaced by a larger one)
+        if (!p) return;
+        for (auto it = allocs.begin(); it != allocs.end(); ++it) if (*it == p) { allocs.erase(it); break; }
+        (void) hipFree(p);
+    }
     ~DeviceScene() {
         for (void *p : allocs) (void) hipFree(p);
         for (auto e : ev_pool) (void) hipEventDestroy(e);
@@ -351,6 +356,7 @@ void device_scene_update_params(DeviceScene *D, const lrt_scene_desc &d) {
 static void ensure_workspace(DeviceScene *D, uint32_t capacity) {
     if (D->capacity >= capacity) return;
     auto alloc_q = [&](DPathStreams &q) {
+        D->release(q.o_maxt); D->release(q.d_eta); D->release(q.tp_pdf); D->release(q.res_flags); D->release(q.lp_lane); D->release(q.rng);
         HIP_CHECK(hipMalloc((void **) &q.o_maxt, (size_t) capacity * 16)); D->track(q.o_maxt);
         HIP_CHECK(hipMalloc((void **) &q.d_eta, (size_t) capacity * 16)); D->track(q.d_eta);
         HIP_CHECK(hipMalloc((void **) &q.tp_pdf, (size_t) capacity * 16)); D->track(q.tp_pdf);
@@ -358,7 +364,8 @@ static void ensure_workspace(DeviceScene *D, uint32_t capacity) {
         HIP_CHECK(hipMalloc((void **) &q.lp_lane, (size_t) capacity * 16)); D->track(q.lp_lane);
         HIP_CHECK(hipMalloc((void **) &q.rng, (size_t) capacity * 8)); D->track(q.rng);
     };
-    alloc_q(D->q[0]); alloc_q(D->q[1]);    // (older, smaller streams stay tracked and are freed with the scene)
+    HIP_CHECK(hipStreamSynchronize(D->stream));
+    alloc_q(D->q[0]); alloc_q(D->q[1]);
     D->capacity = capacity;
 }
 
@@ -408,10 +415,11 @@ static void ensure_pixel_list(DeviceScene *D, const ResolvedOpts &O) {
 
 static void ensure_prb_workspace(DeviceScene *D, uint32_t records, uint64_t l_buf_lanes) {
     if (D->prb_capacity < records) {
-        for (int k = 0; k < 2; ++k) { HIP_CHECK(hipMalloc((void **) &D->dl[k], (size_t) records * 16)); D->track(D->dl[k]); }
+        HIP_CHECK(hipStreamSynchronize(D->stream));
+        for (int k = 0; k < 2; ++k) { D->release(D->dl[k]); HIP_CHECK(hipMalloc((void **) &D->dl[k], (size_t) records * 16)); D->track(D->dl[k]); }
         D->prb_capacity = records;
     }
-    if (D->l_buf_lanes < l_buf_lanes) { HIP_CHECK(hipMalloc((void **) &D->L_buf, (size_t) l_buf_lanes * 16)); D->track(D->L_buf); D->l_buf_lanes = l_buf_lanes; }
+    if (D->l_buf_lanes < l_buf_lanes) { HIP_CHECK(hipStreamSynchronize(D->stream)); D->release(D->L_buf); HIP_CHECK(hipMalloc((void **) &D->L_buf, (size_t) l_buf_lanes * 16)); D->track(D->L_buf); D->l_buf_lanes = l_buf_lanes; }
     if (!D->d_grads) { HIP_CHECK(hipMalloc((void **) &D->d_grads, 7 * sizeof(double))); D->track(D->d_grads); }
 }
 
