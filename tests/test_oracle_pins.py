@@ -261,6 +261,20 @@ def _cube():
     return v, f
 
 
+def test_cornell_1080_weak_golden(mi, orc):
+    """Weak image golden for config C2: the reference tree's own 1080x1080 Cornell render (8-bit sRGB PNG; spp, depth and
+    variant are not recorded), decoded to linear and box-averaged 8x8 (tests/golden/make_cornell_1080_small.py), against
+    the oracle at 135x135.  It pins geometry, materials and light transport at the few-percent level only."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "reference_cornell_box_1080_down8.npy")).astype(np.float64)
+    d = mi.cornell_box(); d['sensor']['film'].update({'width': 135, 'height': 135})
+    img = orc.OrcScene(mi.load_dict(d)).render(spp=128, seed=0).astype(np.float64)[..., :3]
+    c = np.clip(img, 0, 1)
+    ok = (g < 0.9).all(-1) & (c < 0.9).all(-1)                  # away from the clipped emitter
+    assert np.allclose(c[ok].mean(0), g[ok].mean(0), rtol=0.10)
+    assert np.corrcoef(c[ok].ravel(), g[ok].ravel())[0, 1] > 0.995
+    assert np.abs(c - g)[ok].mean() < 0.06 * g[ok].mean()
+
+
 @pytest.mark.parametrize("integrator", ["path", "volpath"])
 def test_white_furnace_surface(mi, orc, integrator):
     """Reflectance-1 diffuse cube under a radiance-1 constant environment: every pixel converges to 1."""
