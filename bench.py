@@ -41,6 +41,24 @@ def parse():
     return p.parse_args()
 
 
+def usable_cores():
+    """Host cores this process may actually use: the affinity mask, capped by the cgroup CPU quota (the GPU boxes expose
+    all cores of the host but grant a share of them)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max": n = min(n, max(1, int(float(txt[0]) / float(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0]); per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0: n = min(n, max(1, int(q / per + 0.5)))
+            break
+        except Exception:
+            continue
+    return max(1, n)
+
+
 def main():
     a = parse()
     import torch
@@ -138,7 +156,7 @@ def main():
         # ---- CPU baseline: the oracle (our restatement of the reference's CPU path) on the host cores,
         # same scene/resolution at a reduced spp, and the GPU-vs-oracle RMSE at that spp (same seed).
         import orc
-        cores = os.cpu_count() or 1
+        cores = usable_cores()
         if a.cpu_spp <= 0:                       # calibrate on 1 spp so that the sample takes ~15 s of wall time
             cs = mi.load_file(a.scene, integrator=a.integrator, spp=1, res_width=a.width, res_height=a.height)
             t1 = time.perf_counter(); orc.OrcScene(cs).render(threads=cores, spp=1, seed=0); c1 = time.perf_counter() - t1
