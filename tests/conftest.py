@@ -12,6 +12,7 @@ SCENES = os.path.join(ROOT, "scenes")
 LIVER_XML = os.path.join(SCENES, "Liver-SingleMesh", "mitsuba3", "scene.xml")
 PARENCHYMA_XML = os.path.join(SCENES, "Parenchyma", "mitsuba3", "scene.xml")
 GLISSON_XML = os.path.join(SCENES, "GlissonCapsule", "mitsuba3", "scene.xml")
+REALTIME_XML = os.path.join(SCENES, "Liver-SingleMesh-Realtime", "mitsuba3", "scene.xml")
 MULTIMESH_XML = os.path.join(SCENES, "Liver-MultiMesh", "mitsuba3", "scene.xml")
 
 

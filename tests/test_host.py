@@ -8,7 +8,7 @@ import re
 import numpy as np
 import pytest
 
-from conftest import GLISSON_XML, ROOT, LIVER_XML, PARENCHYMA_XML, MULTIMESH_XML
+from conftest import GLISSON_XML, REALTIME_XML, ROOT, LIVER_XML, PARENCHYMA_XML, MULTIMESH_XML
 
 
 def test_library_exports_every_declared_symbol(mi):
@@ -159,6 +159,8 @@ def test_other_scene_files_load(mi):
     sg = mi.load_file(GLISSON_XML, integrator="volpath"); g = sg.desc          # src/media/glissonCapsule.cpp:142-144,196-197
     assert g.media[0].has_spectral_extinction == 1 and g.media[0].sample_emitters == 1 and g.sampler_type == 1 and g.sample_count == 64
     assert (g.film.width, g.film.height, g.film.rfilter) == (1280, 720, 2) and g.integrator.max_depth == 65
+    sr = mi.load_file(REALTIME_XML, integrator="volpath"); r = sr.desc          # same scene, rr_depth = max_depth, 1 spp at 1920x1080
+    assert (r.film.width, r.film.height, r.sample_count, r.integrator.rr_depth, r.integrator.max_depth) == (1920, 1080, 1, 12, 12)
     sm = mi.load_file(MULTIMESH_XML, integrator="path"); m = sm.desc
     assert m.n_faces == 2400 and m.shapes[0].interior_medium == -1
 

@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import LIVER_XML, PARENCHYMA_XML, MULTIMESH_XML, GLISSON_XML, ROOT
+from conftest import LIVER_XML, PARENCHYMA_XML, MULTIMESH_XML, GLISSON_XML, REALTIME_XML, ROOT
 from test_oracle_pins import _stairs, stairs_rays, _cube
 
 pytestmark = pytest.mark.gpu
@@ -121,6 +121,11 @@ def test_liver_volpath_hg_and_params_bit_exact(mi, orc):
     assert_lanes_equal(sc, o, center_lane(sc, 16, 0.4), 1 << 16)
     o.param_set("LiverMedium.phase_function.g", -0.4); sc.param_set("LiverMedium.phase_function.g", -0.4)
     assert_lanes_equal(sc, o, center_lane(sc, 16, 0.5), 1 << 15, seed=2)
+
+
+def test_realtime_scene_bit_exact(mi, orc):
+    sc = mi.load_file(REALTIME_XML, integrator="volpath", spp=4, res_width=192, res_height=108)      # rr_depth = max_depth = 12
+    assert_lanes_equal(sc, orc.OrcScene(sc), 0, 192 * 108 * 4)
 
 
 def test_parenchyma_and_multimesh_scenes_bit_exact(mi, orc):
