@@ -229,7 +229,7 @@ DeviceScene *device_scene_create(const lrt_scene_desc &d, int device) {
             g.cell = ext / (float) res; g.inv_cell = 1.f / g.cell;
             for (int a = 0; a < 3; ++a) { g.lo[a] = lo[a]; g.n[a] = std::max(1, std::min(res, (int) std::ceil((hi[a] - lo[a]) / g.cell))); }
             const size_t n_cells = (size_t) g.n[0] * g.n[1] * g.n[2];
-            float *buf = nullptr; HIP_CHECK(hipMalloc((void **) &buf, n_cells * sizeof(float))); D->track(buf);
+            uint16_t *buf = nullptr; HIP_CHECK(hipMalloc((void **) &buf, n_cells * sizeof(uint16_t))); D->track(buf);
             float diag = std::sqrt((hi[0] - lo[0]) * (hi[0] - lo[0]) + (hi[1] - lo[1]) * (hi[1] - lo[1]) + (hi[2] - lo[2]) * (hi[2] - lo[2]));
             float amax = 0.f; for (int a = 0; a < 3; ++a) amax = std::max(amax, std::max(std::fabs(lo[a]), std::fabs(hi[a])));
             const float abs_margin = 1e-4f * diag + 1e-5f * amax;          // >> f32 rounding of positions and of the field itself

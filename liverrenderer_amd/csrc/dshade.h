@@ -200,7 +200,8 @@ DEV float dist_grid_lower_bound(const DDistGrid &g, V3 p) {
     // grid gets a small or negative bound; NaN coordinates give NaN, which proves nothing).
     float fx = (p.x - g.lo[0]) * g.inv_cell, fy = (p.y - g.lo[1]) * g.inv_cell, fz = (p.z - g.lo[2]) * g.inv_cell;
     int ix = min(max((int) fx, 0), g.n[0] - 1), iy = min(max((int) fy, 0), g.n[1] - 1), iz = min(max((int) fz, 0), g.n[2] - 1);
-    float D = g.d[(uint32_t) ((iz * g.n[1] + iy) * g.n[0] + ix)];
+    union { uint16_t u; _Float16 h; } cv; cv.u = g.d[(uint32_t) ((iz * g.n[1] + iy) * g.n[0] + ix)];
+    float D = (float) cv.h;
     float cx = fx - ((float) ix + .5f), cy = fy - ((float) iy + .5f), cz = fz - ((float) iz + .5f);
     return D - __builtin_amdgcn_sqrtf(cx * cx + cy * cy + cz * cz) * (g.cell * 1.001f);   // 1-ulp hardware sqrt: inside the margins
 }

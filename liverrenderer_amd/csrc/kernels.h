@@ -757,7 +757,7 @@ DEV float point_triangle_dist2(V3 p, V3 a, V3 ab, V3 ac) {
 }
 
 __global__ void __launch_bounds__(LRT_BLOCK)
-k_build_dist_grid(const float4 *__restrict__ tris, uint32_t n_slots, DDistGrid g, float *__restrict__ out, float abs_margin) {
+k_build_dist_grid(const float4 *__restrict__ tris, uint32_t n_slots, DDistGrid g, uint16_t *__restrict__ out, float abs_margin) {
     const size_t n_cells = (size_t) g.n[0] * g.n[1] * g.n[2];
     const size_t c = (size_t) blockIdx.x * LRT_BLOCK + threadIdx.x;
     if (c >= n_cells) return;
@@ -771,7 +771,10 @@ k_build_dist_grid(const float4 *__restrict__ tris, uint32_t n_slots, DDistGrid g
         best = fmin_(best, d2);
     }
     float d = __builtin_sqrtf(best) * .999f - abs_margin;
-    out[c] = d > 0.f ? d : 0.f;
+    d = d > 0.f ? fmin_(d, 60000.f) : 0.f;
+    union { uint16_t u; _Float16 h; } cv; cv.h = (_Float16) d;                      // round to nearest, then step down if that went up
+    if ((float) cv.h > d) cv.u -= 1;
+    out[c] = cv.u;
 }
 
 // Film accumulation for reconstruction filters wider than a pixel (Gaussian, tent; imageblock.cpp:174-232,431-500).  The

@@ -1,8 +1,10 @@
 """Summarise a rocprofv3 output directory produced by scripts/profile_bench.sh.
 Prints the kernel-trace stats table, the PMC counters of this library's kernels (per dispatch), derived figures for the
-render kernel, and writes <out>/traffic.json (HBM bytes per launch of the render kernel, corrected as
-MI355X_MICROARCH.md "HBM" prescribes: FETCH_SIZE x2 on gfx950 for 16-B-per-lane streaming reads, WRITE_SIZE as is;
-both counters are in KiB)."""
+render kernel, and writes <out>/traffic.json (HBM bytes per launch of the render kernel; both counters are in KiB).
+FETCH_SIZE is scaled by FETCH_FACTOR, calibrated on this kernel's own access pattern against a known byte count as
+MI355X_MICROARCH.md "HBM" asks for patterns it did not calibrate (profiles/r01_fetch_size_calibration.txt: the guide's x2
+for one wide streaming read over-corrects here by 1.8x); WRITE_SIZE is read as is."""
+FETCH_FACTOR = 1.118
 import csv, glob, json, os, sys, collections
 out = sys.argv[1]
 def find(pattern):
@@ -33,8 +35,8 @@ for k in agg:
     if "SQ_WAIT_ANY" in a and "SQ_WAVE_CYCLES" in a:
         print(f"   wave cycles waiting {a['SQ_WAIT_ANY'] / a['SQ_WAVE_CYCLES']:.1%}")
     if "FETCH_SIZE" in a and "WRITE_SIZE" in a:
-        rd, wr = a["FETCH_SIZE"] * 1024 * 2, a["WRITE_SIZE"] * 1024
-        print(f"   HBM traffic per launch: read {rd / 1e9:.2f} GB (FETCH_SIZE x2), write {wr / 1e9:.2f} GB, total {(rd + wr) / 1e9:.2f} GB")
+        rd, wr = a["FETCH_SIZE"] * 1024 * FETCH_FACTOR, a["WRITE_SIZE"] * 1024
+        print(f"   HBM traffic per launch: read {rd / 1e9:.2f} GB (FETCH_SIZE x {FETCH_FACTOR}, calibrated), write {wr / 1e9:.2f} GB, total {(rd + wr) / 1e9:.2f} GB")
         workload = None
         try:
             line = [l for l in open(os.path.join(out, "bench_trace.log")) if l.startswith("{")][-1]
@@ -43,5 +45,6 @@ for k in agg:
             pass
         json.dump({"kernel": k, "workload": workload, "read_bytes_per_launch": rd, "write_bytes_per_launch": wr,
                    "traffic_bytes_per_launch": rd + wr, "bench_args": sys.argv[2:],
-                   "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), KiB; FETCH_SIZE doubled (gfx950 correction)"},
+                   "fetch_factor": FETCH_FACTOR,
+                   "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), KiB; FETCH_SIZE x fetch_factor, calibrated on this kernel (profiles/r01_fetch_size_calibration.txt)"},
                   open(os.path.join(out, "traffic.json"), "w"), indent=1)
