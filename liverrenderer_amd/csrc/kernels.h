@@ -617,8 +617,8 @@ DEV void retire_and_compact_wave(const DScene &sc, const DRenderParams &rp, bool
     }
 }
 
-template <int INTEGRATOR, int BLOCK, bool LDS_BVH, bool LD>
 // 4 waves per SIMD for every variant (128 VGPRs): one 1024-thread workgroup per CU, or four 256-thread ones
+template <int INTEGRATOR, int BLOCK, bool LDS_BVH, bool LD>
 __global__ void __launch_bounds__(BLOCK, 4)
 k_render(DScene sc, DRenderParams rp, DLdsInfo li, DPathStreams q0, DPathStreams q1, uint32_t P, DCounters *__restrict__ cnt,
          const uint32_t *__restrict__ pixel_list, uint64_t lane_begin, float *__restrict__ film, float *__restrict__ sample_out, uint64_t sample_base) {

@@ -292,8 +292,8 @@ DEV V3 lane_delta_L(const DScene &sc, const DRenderParams &rp, uint32_t lane, co
 //                   splat into the film / sample_out when L_buf is null (lrt_render with integrator prbvolpath).
 // ADJOINT == true : replay; finished lanes only retire; the parameter gradients of a tile are summed inside the wave,
 //                   accumulated per workgroup in f64 (LDS) and added to grads[7] once at the end.
-template <bool ADJOINT, int BLOCK, bool LDS_BVH, bool LD>
 // 4 waves per SIMD for every variant (128 VGPRs): one 1024-thread workgroup per CU, or four 256-thread ones
+template <bool ADJOINT, int BLOCK, bool LDS_BVH, bool LD>
 __global__ void __launch_bounds__(BLOCK, 4)
 k_render_prb(DScene sc, DRenderParams rp, DLdsInfo li, DPathStreams q0, DPathStreams q1, float4 *__restrict__ dl0, float4 *__restrict__ dl1, uint32_t P,
              DCounters *__restrict__ cnt, const uint32_t *__restrict__ pixel_list, uint64_t lane_begin,
