@@ -16,6 +16,14 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
         same = (g.view(np.uint32) == c.view(np.uint32)).all(axis=1)
         st = sc.stats()
         ok = same.all() and st["n_iter"] == o.last_stats["n_iter"] and st["n_shadow"] == o.last_stats["n_shadow_needed"]
+        if ok and integ == "prbvolpath":                       # the adjoint too: gradients equal up to summation order
+            h, w, c = sc.film_shape()
+            grad = np.random.default_rng(seed).random((h, w, c)).astype(np.float32) / (h * w * c)
+            gg, gc = sc.render_backward(grad, seed=seed), o.render_backward(grad, seed=seed)
+            for k in ("sigma_t", "albedo"):
+                if not (np.abs(gg[k] - gc[k]).max() <= 3e-4 * max(np.abs(gc[k]).max(), 1e-7)): ok = False
+            if not (abs(gg["g"] - gc["g"]) <= 3e-4 * max(abs(gc["g"]), 1e-6) + 1e-9): ok = False
+            if not ok: print(f"seed {seed}: gradient mismatch {gg} vs {gc}", flush=True)
         if not ok:
             bad += 1
             print(f"seed {seed} ({integ}): {int((~same).sum())} lanes differ, n_iter {st['n_iter']} vs {o.last_stats['n_iter']}, n_shadow {st['n_shadow']} vs {o.last_stats['n_shadow_needed']}", flush=True)

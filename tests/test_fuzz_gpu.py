@@ -88,6 +88,13 @@ def test_random_scene_bit_exact(mi, orc, seed):
     sc = mi.load_string(xml)
     o = orc.OrcScene(sc)
     assert_lanes_equal(sc, o, 0, 48 * 40 * 16, seed=seed)
+    if integrator == "prbvolpath":                              # the adjoint too: gradients equal up to summation order
+        h, w, c = sc.film_shape()
+        grad = np.random.default_rng(seed).random((h, w, c)).astype(np.float32) / (h * w * c)
+        gg, gc = sc.render_backward(grad, seed=seed), o.render_backward(grad, seed=seed)
+        for k in ("sigma_t", "albedo"):
+            assert np.abs(gg[k] - gc[k]).max() <= 3e-4 * max(np.abs(gc[k]).max(), 1e-7), (k, gg[k], gc[k])
+        assert abs(gg["g"] - gc["g"]) <= 3e-4 * max(abs(gc["g"]), 1e-6) + 1e-9
     if seed % 4 == 0 and integrator != "prbvolpath":           # the film path too (all three filters appear)
         raw = sc.render(return_raw=True, seed=seed)[1]
         assert film_close(raw, o.render(return_raw=True, seed=seed)[1]).all()
