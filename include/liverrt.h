@@ -162,7 +162,8 @@ typedef struct {
     uint32_t sample_count;        /* sampler sample_count (default spp)            */
     uint32_t sampler_seed;        /* sampler `seed` property (m_base_seed)         */
     uint32_t sampler_type;        /* LRT_SAMPLER_*; ld rounds spp up to 4, 16, 64, 256, 1024, ... */
-    uint32_t pad0;
+    uint32_t samples_per_pass;    /* integrator `samples_per_pass` (integrator.cpp:176-184), 0: unset; renders of more than
+                                     2^32 - 1 samples are split into passes as well (integrator.cpp:275-293)  */
 } lrt_scene_desc;
 
 /* ----------------------------------------------------------- render call */

@@ -39,6 +39,8 @@ struct DeviceScene {
     DCounters *h_counters = nullptr;       // pinned
     float *film = nullptr; size_t film_floats = 0;
     float *image = nullptr; size_t image_floats = 0;
+    unsigned long long *pass_state[2] = { nullptr, nullptr }; uint64_t pass_state_lanes = 0;   // multi-pass renders: per-lane PCG32 states
+    const unsigned long long *cur_pass_in = nullptr; unsigned long long *cur_pass_out = nullptr;
     uint32_t *pixel_slot = nullptr;         // inverse of pixel_list (pixel -> index in the list), tile-sharded renders
     uint32_t *pixel_list = nullptr; uint32_t pixel_list_rank = 0xffffffffu, pixel_list_count = 0, n_owned_pixels = 0;
     std::vector<hipEvent_t> ev_pool;
@@ -374,7 +376,8 @@ static hipEvent_t get_event(DeviceScene *D, size_t i) {
     return D->ev_pool[i];
 }
 
-struct ResolvedOpts { int integrator, max_depth, rr_depth, hide_emitters; uint32_t spp, seed, tile_rank, tile_count; };
+// spp: samples of ONE pass; spp_total = n_passes * spp (integrator.cpp:176-184,275-293)
+struct ResolvedOpts { int integrator, max_depth, rr_depth, hide_emitters; uint32_t spp, seed, tile_rank, tile_count; uint32_t spp_total = 0, n_passes = 1, pass = 0; };
 static ResolvedOpts resolve(const lrt_scene_desc &d, const lrt_render_opts *o) {
     ResolvedOpts r;
     r.integrator = (o && o->integrator >= 0) ? o->integrator : d.integrator.type;
@@ -391,6 +394,16 @@ static ResolvedOpts resolve(const lrt_scene_desc &d, const lrt_render_opts *o) {
     r.tile_rank = o ? o->tile_rank : 0; r.tile_count = (o && o->tile_count) ? o->tile_count : 1;
     if (r.tile_rank >= r.tile_count) throw std::runtime_error("tile_rank must be smaller than tile_count");
     if (r.spp == 0) throw std::runtime_error("spp must be positive");
+    // passes: the integrator's `samples_per_pass`, then the 2^32 - 1 limit of a wavefront (whole image, not this rank's share)
+    r.spp_total = r.spp; r.n_passes = 1; r.pass = 0;
+    if (r.integrator != LRT_INTEGRATOR_PRBVOLPATH) {
+        uint32_t per = d.samples_per_pass ? std::min(d.samples_per_pass, r.spp) : r.spp;
+        if (r.spp % per != 0) throw std::runtime_error("sample_count (" + std::to_string(r.spp) + ") must be a multiple of spp_per_pass (" + std::to_string(per) + ").");
+        const uint64_t wavefront = (uint64_t) d.film.crop_width * d.film.crop_height * per, limit = 0xffffffffull;
+        if (wavefront > limit) per /= (uint32_t) ((wavefront + limit - 1) / limit);
+        if (per == 0) throw std::runtime_error("film too large: a single sample per pixel exceeds 2^32 lanes");
+        r.n_passes = r.spp_total / per; r.spp = per;
+    }
     return r;
 }
 
@@ -429,7 +442,7 @@ static DRenderParams make_params(const lrt_scene_desc &d, const ResolvedOpts &O,
     rp.spp = O.spp; rp.log2_spp = ((O.spp & (O.spp - 1)) == 0) ? (uint32_t) __builtin_ctz(O.spp) : 0xffffffffu;
     rp.profile = (getenv("LRT_DEBUG_LAUNCH") ? 1u : 0u) | (getenv("LRT_EXP") ? (uint32_t) atoi(getenv("LRT_EXP")) : 0u);
     rp.seed_value = d.sampler_seed + O.seed; rp.base_seed = d.sampler_seed; rp.seed = O.seed;
-    rp.ld_count = d.sampler_type == LRT_SAMPLER_LD ? O.spp : 0u; rp.tile_rank = O.tile_rank; rp.tile_count = O.tile_count; rp.n_lanes = n_lanes;
+    rp.ld_count = d.sampler_type == LRT_SAMPLER_LD ? O.spp_total : 0u; rp.pass_index = O.pass; rp.spp_total = O.spp_total; rp.tile_rank = O.tile_rank; rp.tile_count = O.tile_count; rp.n_lanes = n_lanes;
     return rp;
 }
 
@@ -488,7 +501,8 @@ static void run_wavefront(DeviceScene *D, const lrt_scene_desc &d, const Resolve
                           const uint32_t *pixel_list, float *film, float *sample_out, lrt_render_stats &stats) {
     hipStream_t st = D->stream;
     DRenderParams rp = make_params(d, O, n_lanes);
-    rp.pixel_slot = (sample_out && pixel_list) ? D->pixel_slot : nullptr;
+    rp.pixel_slot = pixel_list ? D->pixel_slot : nullptr;
+    rp.pass_in = D->cur_pass_in; rp.pass_out = D->cur_pass_out;
     const bool prb = O.integrator == LRT_INTEGRATOR_PRBVOLPATH;
     PoolGeometry g = pool_geometry(D, n_lanes);
     if (prb && D->use_lds) g.block = 1024;
@@ -529,32 +543,48 @@ void device_render(DeviceScene *D, const lrt_scene_desc &d, const lrt_render_opt
     bool on_device = opts && opts->output_on_device;
     size_t np = (size_t) F.width * F.height, film_floats = np * F.channels, image_floats = np * (F.has_alpha ? 4 : 3);
     ensure_pixel_list(D, O);
-    uint64_t n_lanes = (uint64_t) D->n_owned_pixels * O.spp;
-    if ((uint64_t) np * O.spp > 0xffffffffull) throw std::runtime_error("more than 2^32 samples per render: split into passes (src/render/integrator.cpp:279-293)");
+    const uint64_t n_lanes = (uint64_t) D->n_owned_pixels * O.spp;            // this rank's lanes of ONE pass
     float *film = nullptr;
     if (on_device && film_raw) film = film_raw;
     else { if (D->film_floats < film_floats) { HIP_CHECK(hipMalloc((void **) &D->film, film_floats * 4)); D->track(D->film); D->film_floats = film_floats; } film = D->film; }
     HIP_CHECK(hipMemsetAsync(film, 0, film_floats * 4, D->stream));
     const uint32_t *pixel_list = O.tile_count > 1 ? D->pixel_list : nullptr;
-    if (F.rfilter == LRT_RFILTER_BOX || getenv("LRT_NO_LANE_SPLAT")) run_wavefront(D, d, O, 0, n_lanes, pixel_list, film, nullptr, stats);
-    else {
-        // wide reconstruction filters: per-lane radiance first (16 B / lane, passes of at most 2^28 lanes), then an in-order
+    const bool carry = O.n_passes > 1 && d.sampler_type != LRT_SAMPLER_LD;     // the independent sampler's streams run on from pass to pass
+    if (carry && D->pass_state_lanes < n_lanes) {
+        HIP_CHECK(hipStreamSynchronize(D->stream));
+        for (int k = 0; k < 2; ++k) { D->release(D->pass_state[k]); HIP_CHECK(hipMalloc((void **) &D->pass_state[k], std::max<uint64_t>(n_lanes, 1) * 8)); D->track(D->pass_state[k]); }
+        D->pass_state_lanes = n_lanes;
+    }
+    const bool lane_splat = F.rfilter != LRT_RFILTER_BOX && (O.n_passes > 1 || !getenv("LRT_NO_LANE_SPLAT"));
+    lrt_render_stats total{};
+    for (uint32_t pass = 0; pass < O.n_passes; ++pass) {                       // integrator.cpp:343-353
+        O.pass = pass;
+        D->cur_pass_in = carry ? D->pass_state[pass & 1] : nullptr;
+        D->cur_pass_out = (carry && pass + 1 < O.n_passes) ? D->pass_state[(pass & 1) ^ 1] : nullptr;
+        if (!lane_splat) {
+            lrt_render_stats st1{};
+            run_wavefront(D, d, O, 0, n_lanes, pixel_list, film, nullptr, st1);
+            total.n_samples += st1.n_samples; total.n_iter += st1.n_iter; total.n_shadow += st1.n_shadow; total.n_launches += st1.n_launches;
+            total.n_records += st1.n_records; total.kernel_ms += st1.kernel_ms; total.total_ms += st1.total_ms;
+            continue;
+        }
+        // wide reconstruction filters: per-lane radiance first (16 B / lane, chunks of at most 2^28 lanes), then an in-order
         // splat pass that reduces each pixel's samples inside the wave (k_splat_lanes)
-        const uint64_t pass = std::min<uint64_t>(std::max<uint64_t>(n_lanes, 1), 1ull << 28);
-        ensure_prb_workspace(D, 0, pass);
-        lrt_render_stats total{};
-        for (uint64_t base = 0; base < n_lanes; base += pass) {
-            const uint64_t n = std::min<uint64_t>(pass, n_lanes - base);
+        const uint64_t chunk = std::min<uint64_t>(std::max<uint64_t>(n_lanes, 1), 1ull << 28);
+        ensure_prb_workspace(D, 0, chunk);
+        for (uint64_t base = 0; base < n_lanes; base += chunk) {
+            const uint64_t n = std::min<uint64_t>(chunk, n_lanes - base);
             lrt_render_stats st1{};
             run_wavefront(D, d, O, base, n, pixel_list, nullptr, reinterpret_cast<float *>(D->L_buf), st1);
-            DRenderParams rp = make_params(d, O, n);
+            DRenderParams rp = make_params(d, O, n); rp.pass_in = D->cur_pass_in;
             k_splat_lanes<false><<<(uint32_t) ((n + LRT_BLOCK - 1) / LRT_BLOCK), LRT_BLOCK, 0, D->stream>>>(D->sc, rp, D->L_buf, pixel_list, base, n, film);
             HIP_CHECK(hipGetLastError());
             total.n_samples += st1.n_samples; total.n_iter += st1.n_iter; total.n_shadow += st1.n_shadow; total.n_launches += st1.n_launches;
             total.n_records += st1.n_records; total.kernel_ms += st1.kernel_ms; total.total_ms += st1.total_ms;
         }
-        stats = total;
     }
+    D->cur_pass_in = nullptr; D->cur_pass_out = nullptr;
+    stats = total;
     if (image) {
         float *img = image;
         if (!on_device) { if (D->image_floats < image_floats) { HIP_CHECK(hipMalloc((void **) &D->image, image_floats * 4)); D->track(D->image); D->image_floats = image_floats; } img = D->image; }

@@ -109,7 +109,11 @@ struct DRenderParams {
     uint32_t tile_rank, tile_count;
     uint32_t tiles_x, tiles_y, profile;   // profile: per-region tile timing into DCounters (developer aid, LRT_DEBUG_LAUNCH)
     uint64_t n_lanes;          // lanes this launch renders
-    const uint32_t *pixel_slot; // tile-sharded renders: pixel -> index in the rank's pixel list (per-lane output), else null
+    const uint32_t *pixel_slot; // tile-sharded renders: pixel -> index in the rank's pixel list (rank-local lane index), else null
+    // multi-pass renders (integrator.cpp:176-184,275-293,343-353): spp above is the samples of ONE pass
+    uint32_t pass_index, spp_total;
+    const unsigned long long *pass_in;   // independent sampler: every lane's PCG32 state at the start of this pass (pass > 0)
+    unsigned long long *pass_out;        // ... and where finished paths leave it for the next pass (null: last / only pass)
 };
 
 // Path-state streams (SoA, one float4 / uint2 per path and stream)

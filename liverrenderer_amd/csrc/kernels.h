@@ -42,7 +42,7 @@ DEV uint64_t lane_rng_inc(const DRenderParams &rp, uint32_t lane) {
     if (LD) {
         const uint32_t pixel = (rp.log2_spp != 0xffffffffu) ? (lane >> rp.log2_spp) : (lane / rp.spp);
         uint32_t v0, v1; tea32(rp.base_seed, rp.spp * pixel + rp.seed, &v0, &v1);
-        return (uint64_t) v0 | ((uint64_t) (lane - pixel * rp.spp) << 32);
+        return (uint64_t) v0 | ((uint64_t) (rp.pass_index * rp.spp + (lane - pixel * rp.spp)) << 32);    // sampler.cpp:69-72,109-117
     }
     uint32_t v0, v1; tea32(rp.seed_value, lane, &v0, &v1);
     return ((uint64_t) v1 << 1) | 1u;
@@ -58,10 +58,24 @@ template <bool LD>
 DEV SamplerT<LD> lane_rng_resume(const DRenderParams &rp, uint32_t lane, uint64_t state) {
     SamplerT<LD> r; r.ld_count = rp.ld_count; r.state = state; r.inc = lane_rng_inc<LD>(rp, lane); return r;
 }
-// the pixel jitter: the sampler's first 2-D sample (integrator.cpp:465), needed again wherever a film footprint is formed
-DEV void lane_jitter(const DRenderParams &rp, uint32_t lane, float &jx, float &jy) {
-    if (rp.ld_count) { SamplerT<true> r = lane_rng_fresh<true>(rp, lane); r.next2(jx, jy); }
-    else { SamplerT<false> r = lane_rng_fresh<false>(rp, lane); r.next2(jx, jy); }
+// Rank-local index of a lane within the current pass (the index space of per-lane buffers)
+DEV uint64_t lane_local_index(const DRenderParams &rp, uint32_t lane) {
+    if (!rp.pixel_slot) return lane;
+    const uint32_t pixel = (rp.log2_spp != 0xffffffffu) ? (lane >> rp.log2_spp) : (lane / rp.spp);
+    return (uint64_t) rp.pixel_slot[pixel] * rp.spp + (lane - pixel * rp.spp);
+}
+// The sampler of a lane at the start of the current pass: freshly seeded in pass 0; in later passes the independent sampler
+// continues from the state its path of the previous pass left (Sampler::advance() does not reseed), index j = rank-local lane.
+template <bool LD>
+DEV SamplerT<LD> lane_rng_pass_start(const DRenderParams &rp, uint32_t lane, uint64_t j) {
+    SamplerT<LD> r = lane_rng_fresh<LD>(rp, lane);
+    if (!LD && rp.pass_index > 0) r.state = rp.pass_in[j];
+    return r;
+}
+// the pixel jitter: the sampler's first 2-D sample of the pass (integrator.cpp:465), needed again wherever a film footprint is formed
+DEV void lane_jitter(const DRenderParams &rp, uint32_t lane, uint64_t j, float &jx, float &jy) {
+    if (rp.ld_count) { SamplerT<true> r = lane_rng_pass_start<true>(rp, lane, j); r.next2(jx, jy); }
+    else { SamplerT<false> r = lane_rng_pass_start<false>(rp, lane, j); r.next2(jx, jy); }
 }
 
 // lane -> pixel (src/render/integrator.cpp:321-338); tile-sharded renders go
@@ -98,7 +112,7 @@ DEV PathState generate_camera_path(const DScene &sc, const DRenderParams &rp, co
     uint32_t lane;
     if (pixel_list) { uint32_t pj = (uint32_t) (j / rp.spp); lane = pixel_list[pj] * rp.spp + (uint32_t) (j - (uint64_t) pj * rp.spp); }
     else lane = (uint32_t) j;
-    SamplerT<LD> rng = lane_rng_fresh<LD>(rp, lane);
+    SamplerT<LD> rng = lane_rng_pass_start<LD>(rp, lane, j);
     int px, py; lane_to_pixel(sc, rp, lane, &px, &py);
     float jx, jy; rng.next2(jx, jy);
     float spx = (float) px + jx, spy = (float) py + jy;
@@ -138,8 +152,7 @@ DEV void finish_path(const DScene &sc, const DRenderParams &rp, float *__restric
                      uint64_t sample_base, uint32_t lane, V3 L, bool valid) {
     if (rp.integrator == LRT_INTEGRATOR_PATH && !valid) L = V3(0.f);                 // path.cpp:342-345
     if (sample_out) {                               // per-lane output, indexed by the rank-local lane index
-        uint64_t j = lane;
-        if (rp.pixel_slot) { uint32_t pixel = (rp.log2_spp != 0xffffffffu) ? (lane >> rp.log2_spp) : (lane / rp.spp); j = (uint64_t) rp.pixel_slot[pixel] * rp.spp + (lane - pixel * rp.spp); }
+        const uint64_t j = lane_local_index(rp, lane);
         float4 *o = reinterpret_cast<float4 *>(sample_out) + (j - sample_base);
         *o = make_float4(L.x, L.y, L.z, valid ? 1.f : 0.f);
         return;
@@ -159,7 +172,7 @@ DEV void finish_path(const DScene &sc, const DRenderParams &rp, float *__restric
         if (F.has_alpha) { atomicAdd(p + 3, alpha); atomicAdd(p + 4, 1.f); } else atomicAdd(p + 3, 1.f);
         return;
     }
-    float jx, jy; lane_jitter(rp, lane, jx, jy);
+    float jx, jy; lane_jitter(rp, lane, lane_local_index(rp, lane), jx, jy);
     float spx = (float) px + jx, spy = (float) py + jy;
     int n = F.fn, count = F.fcount;
     int pix = (int) __builtin_floorf(spx) - n, piy = (int) __builtin_floorf(spy) - n;
@@ -479,7 +492,7 @@ DEV bool volpath_iteration(const DScene &sc, const DRenderParams &rp, PathState 
         float q2 = fmin_(max3(throughput) * sqr(eta), .95f);
         if (a2) { float u = pk.next(); a2 = (u < q2) || !(depth > (uint32_t) rp.rr_depth); }
         a2 = a2 && depth < max_depth;
-        if (!a2) { active = false; n_extra += 1; }
+        if (!a2) { active = false; n_extra += 1; rng = pk; }      // the retired trip's Russian-roulette draw stays consumed (multi-pass renders)
         else if (medium >= 0 && sc.grid.enabled) {
             const DMedium M = sc.media[medium];
             MI m2 = medium_sample_interaction(M, ray, pk.next(), channel);
@@ -602,6 +615,7 @@ DEV void retire_and_compact_wave(const DScene &sc, const DRenderParams &rp, bool
                                  const DPathStreams &qout, uint32_t P, uint32_t *s_out /* LDS [3] */) {
     const uint32_t lane_in_wave = threadIdx.x & 63u;
     finish_paths_wave(sc, rp, film, sample_out, sample_base, had_path && !alive, s.lane, s.res, (s.flags & PF_VALID) != 0);
+    if (rp.pass_out && had_path && !alive) rp.pass_out[lane_local_index(rp, s.lane)] = s.rng_state;       // next pass continues this stream
     const int region = !(s.flags & PF_MEDIUM_MASK) ? 2 : ((s.flags & PF_NOHIT) ? 0 : 1);
     const unsigned long long m0 = __ballot(alive && region == 0), m1 = __ballot(alive && region == 1), m2 = __ballot(alive && region == 2);
     uint32_t base = 0;
@@ -804,7 +818,7 @@ k_splat_lanes(DScene sc, DRenderParams rp, const float4 *__restrict__ lane_L, co
             if (rp.integrator == LRT_INTEGRATOR_PATH && alpha == 0.f) L = V3(0.f);     // path.cpp:342-345
         }
         int px, py; lane_to_pixel(sc, rp, lane, &px, &py);
-        float jx, jy; lane_jitter(rp, lane, jx, jy);
+        float jx, jy; lane_jitter(rp, lane, j, jx, jy);
         float spx = (float) px + jx, spy = (float) py + jy;
         pix = (int) __builtin_floorf(spx) - F.fn; piy = (int) __builtin_floorf(spy) - F.fn;
         relx = (float) pix + .5f - spx; rely = (float) piy + .5f - spy;

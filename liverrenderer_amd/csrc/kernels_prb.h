@@ -250,7 +250,7 @@ DEV bool prb_iteration(const DScene &sc, const DRenderParams &rp, PathState &s, 
 // Filter footprint helpers shared by the weight-film and delta_L kernels (imageblock.cpp:431-500)
 DEV void lane_sample_pos(const DScene &sc, const DRenderParams &rp, uint32_t lane, float *spx, float *spy, int *px, int *py) {
     lane_to_pixel(sc, rp, lane, px, py);
-    float jx, jy; lane_jitter(rp, lane, jx, jy);
+    float jx, jy; lane_jitter(rp, lane, lane_local_index(rp, lane), jx, jy);
     *spx = (float) *px + jx; *spy = (float) *py + jy;
 }
 

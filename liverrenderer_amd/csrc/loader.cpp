@@ -544,6 +544,8 @@ struct Loader {
         I.max_depth = get_int(*o, "max_depth", -1); I.rr_depth = get_int(*o, "rr_depth", 5); I.hide_emitters = get_bool(*o, "hide_emitters", false);
         if (I.max_depth < 0 && I.max_depth != -1) fail("\"max_depth\" must be set to -1 (infinite) or a value >= 0");
         if (I.rr_depth <= 0) fail("\"rr_depth\" must be set to a value greater than zero!");
+        int spass = get_int(*o, "samples_per_pass", -1);                      // src/render/integrator.cpp:22-38 (SamplingIntegrator)
+        S.desc.samples_per_pass = spass > 0 ? (uint32_t) spass : 0u;
     }
 
     void run(const std::string &text) {

@@ -1066,7 +1066,8 @@ static void prb_sample(Ctx &C, Ray ray, bool adjoint, V3 delta_L, V3 L_in, V3 *L
 }
 
 /* ------------------------------------------------------------------ film */
-struct Opts { int integrator, max_depth, rr_depth; bool hide_emitters; uint32_t spp, seed; };
+/* spp: samples of ONE pass (= all samples unless the render is split, integrator.cpp:176-184,275-293); spp_total: all passes */
+struct Opts { int integrator, max_depth, rr_depth; bool hide_emitters; uint32_t spp, seed; uint32_t spp_total = 0, n_passes = 1, pass = 0; };
 
 static Opts resolve_opts(const Scene &S, const lrt_render_opts *o) {
     Opts r;
@@ -1077,16 +1078,31 @@ static Opts resolve_opts(const Scene &S, const lrt_render_opts *o) {
     r.spp = (o && o->spp) ? o->spp : S.d.sample_count;
     if (S.d.sampler_type == LRT_SAMPLER_LD) r.spp = ld_round_sample_count(r.spp);      /* integrator.cpp:169-171 */
     r.seed = o ? o->seed : 0;
+    /* passes: `samples_per_pass` (integrator.cpp:176-184), then the 2^32 - 1 wavefront limit (:275-285) */
+    r.spp_total = r.spp; r.n_passes = 1; r.pass = 0;
+    if (r.integrator != LRT_INTEGRATOR_PRBVOLPATH) {
+        uint32_t per = S.d.samples_per_pass ? std::min(S.d.samples_per_pass, r.spp) : r.spp;
+        if (per == 0 || r.spp % per != 0) per = r.spp;               /* the reference throws; callers check with orc_passes_valid() */
+        uint64_t wavefront = (uint64_t) S.d.film.crop_width * S.d.film.crop_height * per, limit = 0xffffffffull;
+        if (wavefront > limit) per /= (uint32_t) ((wavefront + limit - 1) / limit);
+        if (per == 0) per = 1;
+        r.n_passes = r.spp_total / per; r.spp = per;
+    }
     return r;
 }
 
 struct SampleOut { float r, g, b, a; float px, py; };
 
 /* src/render/integrator.cpp:321-338 (lane -> pixel) + :449-521 (render_sample) */
-static SampleOut render_lane(const Scene &S, const Opts &O, uint64_t lane, orc_stats *st) {
+/* carry: per-lane PCG32 state handed from pass to pass (Sampler::advance() does not reseed the independent sampler:
+   pass p + 1 continues every lane's stream where its path of pass p stopped); null for single-pass renders. */
+static SampleOut render_lane(const Scene &S, const Opts &O, uint64_t lane, orc_stats *st, uint64_t *carry = nullptr) {
     const lrt_film_desc &F = S.d.film;
     Ctx C(S); C.max_depth = O.max_depth; C.rr_depth = O.rr_depth; C.hide_emitters = O.hide_emitters;
     C.smp = lane_sampler(S.d.sampler_type, S.d.sampler_seed, O.seed, (uint32_t) lane, O.spp);
+    if (S.d.sampler_type == LRT_SAMPLER_LD) {            /* sampler.cpp:69-72,109-117: sample index = pass * spp_per_pass + lane % spp_per_pass */
+        C.smp.sample_index = O.pass * O.spp + (uint32_t) (lane % O.spp); C.smp.sample_count = O.spp_total;
+    } else if (carry && O.pass > 0) C.smp.rng.state = carry[lane];
     uint32_t idx = (uint32_t) (lane / O.spp);
     uint32_t W = (uint32_t) F.crop_width;
     uint32_t py = idx / W, px = idx - py * W;
@@ -1102,6 +1118,7 @@ static SampleOut render_lane(const Scene &S, const Opts &O, uint64_t lane, orc_s
     else if (O.integrator == LRT_INTEGRATOR_PRBVOLPATH) prb_sample(C, ray, false, V3(0.f), V3(0.f), &L, &valid, nullptr);
     else volpath_sample(C, ray, S.d.sensor.medium, &L, &valid);
     if (st) { st->n_iter += C.n_iter; st->n_shadow += C.n_shadow; st->n_shadow_needed += C.n_shadow_needed; st->n_samples += 1; }
+    if (carry) carry[lane] = C.smp.rng.state;
     SampleOut o; o.r = L.x; o.g = L.y; o.b = L.z; o.a = valid ? 1.f : 0.f;
     bool box = F.rfilter == LRT_RFILTER_BOX;
     o.px = box ? posx : spx; o.py = box ? posy : spy;
@@ -1192,19 +1209,24 @@ extern "C" int orc_render(orc_scene *s, const lrt_render_opts *opts, int n_threa
     const lrt_film_desc &F = S.d.film;
     int C = F.has_alpha ? 5 : 4;
     size_t np = (size_t) F.crop_width * F.crop_height;
-    uint64_t N = (uint64_t) np * O.spp;
+    uint64_t N = (uint64_t) np * O.spp;                                      /* lanes of one pass */
     if (N > 0xffffffffull) { g_err = "orc_render: more than 2^32 lanes"; return 1; }
     std::vector<float> film(np * C, 0.f);
     int nt = hw_threads(n_threads);
     std::vector<orc_stats> st(nt); for (auto &x : st) memset(&x, 0, sizeof(x));
     const uint64_t chunk = 1u << 20;
     std::vector<SampleOut> buf((size_t) std::min<uint64_t>(chunk, N));
-    for (uint64_t base = 0; base < N; base += chunk) {
-        uint64_t cnt = std::min<uint64_t>(chunk, N - base);
-        parallel_for(cnt, nt, [&](uint64_t b, uint64_t e, int t) {
-            for (uint64_t i = b; i < e; ++i) buf[i] = render_lane(S, O, base + i, &st[t]);
-        });
-        for (uint64_t i = 0; i < cnt; ++i) film_put(S, film.data(), buf[i]);   /* lane order: deterministic */
+    std::vector<uint64_t> carry;
+    if (O.n_passes > 1 && S.d.sampler_type != LRT_SAMPLER_LD) carry.resize((size_t) N);
+    for (uint32_t pass = 0; pass < O.n_passes; ++pass) {                     /* integrator.cpp:343-353 */
+        O.pass = pass;
+        for (uint64_t base = 0; base < N; base += chunk) {
+            uint64_t cnt = std::min<uint64_t>(chunk, N - base);
+            parallel_for(cnt, nt, [&](uint64_t b, uint64_t e, int t) {
+                for (uint64_t i = b; i < e; ++i) buf[i] = render_lane(S, O, base + i, &st[t], carry.empty() ? nullptr : carry.data());
+            });
+            for (uint64_t i = 0; i < cnt; ++i) film_put(S, film.data(), buf[i]);   /* lane order: deterministic */
+        }
     }
     if (film_raw) memcpy(film_raw, film.data(), film.size() * sizeof(float));
     if (image) film_develop(S, film.data(), image);
