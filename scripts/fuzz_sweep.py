@@ -11,11 +11,16 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
     xml, integ = random_scene_xml(seed)
     try:
         sc = mi.load_string(xml); o = orc.OrcScene(sc)
-        n = 48 * 40 * 16
+        n = 48 * 40 * min(16, sc.desc.samples_per_pass or 16)
         g = sc.render_samples(0, n, seed=seed); c = o.render_samples(0, n, seed=seed)
         same = (g.view(np.uint32) == c.view(np.uint32)).all(axis=1)
         st = sc.stats()
         ok = same.all() and st["n_iter"] == o.last_stats["n_iter"] and st["n_shadow"] == o.last_stats["n_shadow_needed"]
+        if ok and sc.desc.samples_per_pass:                    # multi-pass: compare the films (all passes)
+            raw = sc.render(return_raw=True, seed=seed)[1]; ora = o.render(return_raw=True, seed=seed)[1]
+            scale = np.maximum(np.abs(ora).max(axis=-1, keepdims=True), 1.0)
+            if not (np.abs(raw - ora) <= 8e-5 * scale).all() or sc.stats()["n_iter"] != o.last_stats["n_iter"]:
+                ok = False; print(f"seed {seed}: multi-pass film mismatch", flush=True)
         if ok and integ == "prbvolpath":                       # the adjoint too: gradients equal up to summation order
             h, w, c = sc.film_shape()
             grad = np.random.default_rng(seed).random((h, w, c)).astype(np.float32) / (h * w * c)
