@@ -28,7 +28,7 @@ static lrt_status fail(lrt_status st, const std::string &msg) { g_error = msg; r
 extern "C" {
 
 const char *lrt_last_error(void) { return g_error.c_str(); }
-int lrt_version(void) { return 100; }
+int lrt_version(void) { return 101; }    // 1.1: sampler_type / samples_per_pass in lrt_scene_desc, n_records in lrt_render_stats, lrt_image_write_png
 
 static std::vector<std::pair<std::string, std::string>> parse_defines(const char *const *defines, int n) {
     std::vector<std::pair<std::string, std::string>> r;
