@@ -127,6 +127,8 @@ typedef struct {
     float   fov_x;            /* horizontal field of view, degrees                 */
     float   near_clip, far_clip;
     int32_t medium;           /* medium the sensor sits in, -1: none               */
+    float   principal_point_offset_x, principal_point_offset_y;   /* perspective.cpp:147-150,214-221 */
+    int32_t pad;
 } lrt_sensor_desc;
 
 typedef struct {

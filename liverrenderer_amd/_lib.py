@@ -44,7 +44,7 @@ class EmitterDesc(C.Structure):
 
 class SensorDesc(C.Structure):
     _fields_ = [("to_world", C.c_float * 16), ("fov_x", C.c_float), ("near_clip", C.c_float), ("far_clip", C.c_float),
-                ("medium", C.c_int32)]
+                ("medium", C.c_int32), ("principal_point_offset_x", C.c_float), ("principal_point_offset_y", C.c_float), ("pad", C.c_int32)]
 
 
 class FilmDesc(C.Structure):

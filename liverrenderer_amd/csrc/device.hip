@@ -91,6 +91,7 @@ static void build_camera(const lrt_scene_desc &d, DCamera &cam, DFilm &film) {
     for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) cam.s2c[4 * i + j] = it[4 * j + i];
     memcpy(cam.to_world, C.to_world, sizeof(float) * 12);
     cam.near_clip = C.near_clip; cam.far_clip = C.far_clip; cam.medium = C.medium;
+    cam.ppo_x = fw * C.principal_point_offset_x / (float) F.crop_width; cam.ppo_y = fh * C.principal_point_offset_y / (float) F.crop_height;
 
     film.width = F.crop_width; film.height = F.crop_height; film.crop_offset_x = F.crop_offset_x; film.crop_offset_y = F.crop_offset_y;
     film.scale_x = 1.f / (float) F.crop_width; film.scale_y = 1.f / (float) F.crop_height;

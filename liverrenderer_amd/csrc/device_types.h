@@ -44,6 +44,7 @@ struct DCamera {
     float to_world[12];        // rows 0..2
     float near_clip, far_clip;
     int32_t medium, pad;
+    float ppo_x, ppo_y;        // film size * principal_point_offset / crop size (perspective.cpp:214-215)
 };
 
 struct DFilm {

@@ -90,7 +90,7 @@ DEV void lane_to_pixel(const DScene &sc, const DRenderParams &rp, uint32_t lane,
 // src/sensors/perspective.cpp:239-279
 DEV Ray camera_ray(const DScene &sc, float ax, float ay) {
     const float *m = sc.cam.s2c;
-    V3 p(ax + 0.f, ay + 0.f, 0.f);
+    V3 p(ax + sc.cam.ppo_x, ay + sc.cam.ppo_y, 0.f);
     float r[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) r[i] = fma_(m[4 * i + 2], p.z, fma_(m[4 * i + 1], p.y, fma_(m[4 * i + 0], p.x, m[4 * i + 3])));

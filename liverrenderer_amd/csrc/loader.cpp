@@ -509,6 +509,7 @@ struct Loader {
         }
         // src/render/sensor.cpp:123-132,142-196 (parse_fov)
         C.near_clip = get_float(*o, "near_clip", 1e-2f); C.far_clip = get_float(*o, "far_clip", 1e4f);
+        C.principal_point_offset_x = get_float(*o, "principal_point_offset_x", 0.f); C.principal_point_offset_y = get_float(*o, "principal_point_offset_y", 0.f);
         if (C.near_clip <= 0.f) fail("The 'near_clip' parameter must be greater than zero!");
         if (C.near_clip >= C.far_clip) fail("The 'near_clip' parameter must be smaller than 'far_clip'.");
         double aspect = F.width / (double) F.height, fov, result;

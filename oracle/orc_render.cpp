@@ -113,7 +113,9 @@ static inline Sampler lane_sampler(int type, uint32_t base_seed, uint32_t seed, 
 /* ---------------------------------------------------------------- sensor */
 /* src/sensors/perspective.cpp:239-279 (differentials unused: volpath.cpp:107, no ray-differential consumers) */
 static Ray sample_ray(const Scene &S, float px, float py) {
-    V3 near_p = xform_point_proj(S.sample_to_camera, V3(px + 0.f, py + 0.f, 0.f));
+    const lrt_film_desc &F = S.d.film;                           /* perspective.cpp:214-221 */
+    float ppx = (float) F.width * S.d.sensor.principal_point_offset_x / (float) F.crop_width, ppy = (float) F.height * S.d.sensor.principal_point_offset_y / (float) F.crop_height;
+    V3 near_p = xform_point_proj(S.sample_to_camera, V3(px + ppx, py + ppy, 0.f));
     V3 d = normalize(near_p);
     Ray r;
     r.o = V3(S.cam_to_world.m[3], S.cam_to_world.m[7], S.cam_to_world.m[11]);

@@ -221,6 +221,19 @@ def test_cropped_film_known_answer(mi):
     assert np.allclose(sc.render(integrator="path", max_depth=1, hide_emitters=True), 0)
 
 
+def test_principal_point_offset(mi, orc):
+    """perspective.cpp:147-150,214-221: the principal point offset shifts the image; lanes bit-exact, and the shifted image is
+    the unshifted one moved by offset x film size pixels."""
+    d = mi.cornell_box(); d['sensor']['film'].update({'width': 64, 'height': 64}); d['sensor']['sampler']['sample_count'] = 16
+    a = mi.load_dict(d)
+    d['sensor']['principal_point_offset_x'] = 0.125; d['sensor']['principal_point_offset_y'] = -0.0625
+    b = mi.load_dict(d)
+    assert b.desc.sensor.principal_point_offset_x == 0.125
+    assert_lanes_equal(b, orc.OrcScene(b), 0, 64 * 64 * 16)
+    ia, ib = a.render(spp=64), b.render(spp=64)
+    assert np.abs(ib[4:60, 0:56] - ia[0:56, 8:64]).mean() < 0.15 * ia.mean()      # same content, moved 8 px left / 4 px down
+
+
 def test_crop_window_matches_full_render_lanes(mi, orc):
     d = mi.cornell_box()
     d['sensor']['film'].update({'crop_offset_x': 40, 'crop_offset_y': 100, 'crop_width': 50, 'crop_height': 30, 'rfilter': {'type': 'box'}})
