@@ -87,8 +87,12 @@ void lrt_scene_free(lrt_scene *scene) {
     delete scene;
 }
 
+// device < 0: whatever device the image already lives on (0 when there is none yet).  A render that names another device
+// than the current one moves the scene there (one process per GPU is the intended use; this keeps a mistake from reading
+// another GPU's pointers).
 static void ensure_device(lrt_scene *s, int device) {
-    if (!s->dev) { s->dev = device_scene_create(s->st.desc, device); s->params_dirty = false; }
+    if (s->dev && device >= 0 && device != s->dev_ordinal) { device_scene_destroy(s->dev); s->dev = nullptr; }
+    if (!s->dev) { s->dev_ordinal = device < 0 ? 0 : device; s->dev = device_scene_create(s->st.desc, s->dev_ordinal); s->params_dirty = false; }
     else if (s->params_dirty) { device_scene_update_params(s->dev, s->st.desc); s->params_dirty = false; }
 }
 
@@ -109,7 +113,7 @@ lrt_status lrt_render_stats_get(const lrt_scene *scene, lrt_render_stats *out) {
 lrt_status lrt_film_develop(lrt_scene *scene, const float *film_raw, float *image, int on_device) {
     if (!scene || !film_raw || !image) return fail(LRT_ERR_INVALID, "lrt_film_develop: null argument");
     LRT_TRY
-        ensure_device(scene, 0);
+        ensure_device(scene, -1);
         device_develop(scene->dev, film_raw, image, on_device);
         return LRT_OK;
     LRT_CATCH
@@ -136,7 +140,7 @@ lrt_status lrt_render_backward(lrt_scene *scene, const lrt_render_opts *opts, co
 lrt_status lrt_trace(lrt_scene *scene, const lrt_rays_soa *rays, const lrt_hits_soa *hits, uint32_t n, int any_hit) {
     if (!scene || !rays || !hits) return fail(LRT_ERR_INVALID, "lrt_trace: null argument");
     LRT_TRY
-        ensure_device(scene, 0);
+        ensure_device(scene, -1);
         device_trace(scene->dev, rays, hits, n, any_hit);
         return LRT_OK;
     LRT_CATCH

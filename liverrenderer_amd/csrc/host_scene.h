@@ -35,5 +35,6 @@ struct lrt_scene {
     lrt::SceneStorage st;
     lrt::DeviceScene *dev = nullptr;     // created lazily on first device call
     bool params_dirty = true;
+    int dev_ordinal = -1;                  // HIP device the device image lives on
     lrt_render_stats stats{};
 };
