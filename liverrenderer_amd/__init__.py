@@ -14,7 +14,7 @@ from . import _lib
 from ._lib import make_opts
 
 __all__ = ["set_variant", "variant", "variants", "load_file", "load_string", "load_dict", "cornell_box", "render",
-           "traverse", "Scene", "ScalarTransform4f", "render_stats"]
+           "traverse", "Scene", "ScalarTransform4f", "render_stats", "Bitmap", "Struct", "util", "read_image", "write_exr", "write_png"]
 
 _VARIANT = "hip_ad_rgb"
 
@@ -443,3 +443,64 @@ def write_exr(path, image):
     if img.ndim == 2:
         img = img[..., None]
     _lib.check(_lib.lib().lrt_image_write_exr(os.fspath(path).encode(), img.shape[1], img.shape[0], img.shape[2], img.ctypes.data))
+
+
+# ---- the handful of image-side names the reference's drivers use (MitsubaRunner.py:166-167, LiverRenderer.py:383-385),
+# so that those scripts run with the import swapped: mi.Bitmap(path | array), Bitmap.convert(RGBA, UInt8, srgb_gamma=True),
+# mi.util.write_bitmap(path, image).  Arrays stay float32 and linear; the sRGB / 8-bit conversion happens in the writer.
+class Struct:
+    class Type:
+        UInt8, Float16, Float32 = "uint8", "float16", "float32"
+
+
+class Bitmap:
+    class PixelFormat:
+        Y, YA, RGB, RGBA = "y", "ya", "rgb", "rgba"
+
+    def __init__(self, src):
+        self.data = read_image(src) if isinstance(src, (str, os.PathLike)) else np.asarray(src, dtype=np.float32)
+        if self.data.ndim == 2:
+            self.data = self.data[..., None]
+        self.component_format, self.srgb_gamma = Struct.Type.Float32, False
+
+    def size(self):
+        return (self.data.shape[1], self.data.shape[0])
+
+    def channel_count(self):
+        return self.data.shape[2]
+
+    def convert(self, pixel_format=None, component_format=None, srgb_gamma=None):
+        """src/core/bitmap.cpp Bitmap::convert, for the conversions the drivers request: channel layout now, the transfer
+        function and the quantisation when the bitmap is written."""
+        d, out = self.data, Bitmap.__new__(Bitmap)
+        n = {"y": 1, "ya": 2, "rgb": 3, "rgba": 4}.get(pixel_format, d.shape[2])
+        if n != d.shape[2]:
+            rgb = d[..., :3] if d.shape[2] >= 3 else np.repeat(d[..., :1], 3, axis=2)
+            alpha = d[..., -1:] if d.shape[2] in (2, 4) else np.ones_like(d[..., :1])
+            lum = (0.212671 * rgb[..., :1] + 0.715160 * rgb[..., 1:2] + 0.072169 * rgb[..., 2:3])
+            d = {1: lum, 2: np.concatenate([lum, alpha], 2), 3: rgb, 4: np.concatenate([rgb, alpha], 2)}[n]
+        out.data = np.ascontiguousarray(d, dtype=np.float32)
+        out.component_format = component_format or self.component_format
+        out.srgb_gamma = self.srgb_gamma if srgb_gamma is None else bool(srgb_gamma)
+        return out
+
+    def write(self, path):
+        util.write_bitmap(path, self)
+
+    def __array__(self, dtype=None):
+        return self.data if dtype is None else self.data.astype(dtype)
+
+
+class util:
+    @staticmethod
+    def write_bitmap(path, image, write_async=False):
+        """src/python/python/util.py write_bitmap: 8-bit formats get the sRGB transfer function, EXR stays linear float."""
+        data = image.data if isinstance(image, Bitmap) else np.asarray(image, dtype=np.float32)
+        if os.fspath(path).lower().endswith(".png"):
+            write_png(path, data)
+        elif os.fspath(path).lower().endswith(".exr"):
+            write_exr(path, data)
+        else:
+            raise RuntimeError(f"write_bitmap: unsupported file format \"{path}\" (supported: .png, .exr)")
+
+    cornell_box = staticmethod(lambda: cornell_box())

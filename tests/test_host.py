@@ -140,6 +140,22 @@ def test_png_export_matches_reference_rendition(mi, tmp_path):
         assert np.abs(np.round(back * 255) - np.round(q * 255)).max() <= 1
 
 
+def test_driver_image_calls(mi, tmp_path):
+    """The image-side calls of the reference's drivers (MitsubaRunner.py:166-167, LiverRenderer.py:383-385) with the import swapped."""
+    img = np.random.default_rng(1).random((6, 10, 3)).astype(np.float32)
+    mi.util.write_bitmap(str(tmp_path / "a.exr"), img)
+    mi.util.write_bitmap(str(tmp_path / "a.png"), img)
+    assert (mi.read_image(tmp_path / "a.exr") == img).all()
+    bmp = mi.Bitmap(str(tmp_path / "a.exr"))
+    bmp = bmp.convert(mi.Bitmap.PixelFormat.RGBA, mi.Struct.Type.UInt8, srgb_gamma=True)
+    assert bmp.channel_count() == 4 and bmp.size() == (10, 6) and (np.asarray(bmp)[..., 3] == 1).all()
+    mi.util.write_bitmap(str(tmp_path / "b.png"), bmp, write_async=False)
+    a, b = mi.read_image(tmp_path / "a.png"), mi.read_image(tmp_path / "b.png")
+    assert b.shape == (6, 10, 4) and (b[..., :3] == a).all() and (b[..., 3] == 1).all()
+    srgb = np.where(img <= 0.0031308, 12.92 * img, 1.055 * img ** (1 / 2.4) - 0.055)
+    assert np.abs(np.round(a * 255) - np.round(srgb * 255)).max() <= 1
+
+
 def test_exr_writer_roundtrip(mi, tmp_path):
     rng = np.random.default_rng(0)
     for ch in (1, 3, 4):
