@@ -431,6 +431,36 @@ def test_lookahead_is_invisible_in_statistics(mi, monkeypatch):
     assert film_close(ra, rb).all()
 
 
+# ------------------------------------------------------------------------ edge cases
+def test_edge_case_scenes(mi, orc):
+    """Degenerate inputs the reference accepts: no geometry at all (environment only), no emitter at all (black image), a
+    1x1 film, 1 spp, a non-power-of-two spp with a crop window that leaves a single column."""
+    env_only = """<scene version="3.0.0"><integrator type="volpath"/>
+      <sensor type="perspective"><sampler type="independent"><integer name="sample_count" value="3"/></sampler>
+        <film type="hdrfilm"><integer name="width" value="9"/><integer name="height" value="5"/><rfilter type="box"/></film></sensor>
+      <emitter type="constant"><rgb name="radiance" value="0.25, 0.5, 1"/></emitter></scene>"""
+    sc = mi.load_string(env_only)
+    g = assert_lanes_equal(sc, orc.OrcScene(sc), 0, 9 * 5 * 3)
+    assert (g[:, :3] == np.float32([0.25, 0.5, 1.0])).all() and (g[:, 3] == 1).all()
+    img = sc.render()
+    assert np.allclose(img, [0.25, 0.5, 1.0])
+    dark = env_only.replace('<emitter type="constant"><rgb name="radiance" value="0.25, 0.5, 1"/></emitter>',
+                            '<shape type="cube"><bsdf type="diffuse"/></shape>').replace('type="volpath"', 'type="path"')
+    sc = mi.load_string(dark)
+    g = assert_lanes_equal(sc, orc.OrcScene(sc), 0, 9 * 5 * 3)
+    assert (g[:, :3] == 0).all() and (sc.render() == 0).all()
+    d = mi.cornell_box(); d['sensor']['film'].update({'width': 1, 'height': 1}); d['sensor']['sampler']['sample_count'] = 1
+    sc = mi.load_dict(d)
+    assert_lanes_equal(sc, orc.OrcScene(sc), 0, 1)
+    assert sc.render().shape == (1, 1, 3)
+    d = mi.cornell_box(); d['sensor']['film'].update({'width': 33, 'height': 17, 'crop_offset_x': 20, 'crop_offset_y': 3, 'crop_width': 1, 'crop_height': 11})
+    d['sensor']['sampler']['sample_count'] = 7
+    sc = mi.load_dict(d); o = orc.OrcScene(sc)
+    assert sc.film_shape()[:2] == (11, 1)
+    assert_lanes_equal(sc, o, 0, 11 * 7)
+    assert film_close(sc.render(return_raw=True)[1], o.render(return_raw=True)[1]).all()
+
+
 # -------------------------------------------------------------------- error paths
 def test_error_reporting(mi, cornell):
     with pytest.raises(RuntimeError, match="tile_rank"):
