@@ -431,6 +431,26 @@ def test_lookahead_is_invisible_in_statistics(mi, monkeypatch):
     assert film_close(ra, rb).all()
 
 
+# ------------------------------------------------------- scenes from POD descriptions
+def test_scene_from_desc_round_trip(mi, orc):
+    """`lrt_scene_from_desc` (the "from buffers" entry of the ABI) with everything a description can hold: the POD
+    description of a scene loaded from XML creates a second, independent scene whose lanes are bit-identical."""
+    import ctypes as C
+    from liverrenderer_amd import _lib
+    for src in (mi.load_file(LIVER_XML, integrator="volpath", spp=8, res_width=96, res_height=54),
+                mi.load_file(PARENCHYMA_XML, integrator="volpath", spp=16, res_width=96, res_height=54),
+                mi.load_string(fog_xml(rf="tent")), mi.load_dict(mi.cornell_box())):
+        h = C.c_void_p()
+        _lib.check(_lib.lib().lrt_scene_from_desc(C.byref(src.desc), C.byref(h)))
+        copy = mi.Scene(h.value)
+        n = min(1 << 14, src.film_shape()[0] * src.film_shape()[1] * src.spp)
+        a, b = src.render_samples(0, n, seed=3), copy.render_samples(0, n, seed=3)
+        assert (bits(a) == bits(b)).all()
+        assert copy.desc.n_faces == src.desc.n_faces and copy.desc.sampler_type == src.desc.sampler_type
+        ia, ib = src.render(spp=4, seed=1), copy.render(spp=4, seed=1)
+        assert np.allclose(ia, ib, rtol=1e-4, atol=1e-5)
+
+
 # ------------------------------------------------------------------------ edge cases
 def test_edge_case_scenes(mi, orc):
     """Degenerate inputs the reference accepts: no geometry at all (environment only), no emitter at all (black image), a
