@@ -174,7 +174,8 @@ typedef struct {
     int32_t  max_depth;       /* -2: use the scene's                               */
     int32_t  rr_depth;        /* -1: use the scene's                               */
     int32_t  hide_emitters;   /* -1: use the scene's                               */
-    uint32_t spp;             /* 0: use the scene's sample_count                   */
+    uint32_t spp;             /* 0: use the scene's sample_count; with the ld sampler
+                                 rounded up to 4, 16, 64, 256, ... (ldsampler.cpp:83-93)  */
     uint32_t seed;
     /* image-tile sharding (multi-GPU): this call renders only the 32x32 pixel
        tiles t with t % tile_count == tile_rank, into a full-size zeroed film. */
@@ -224,8 +225,9 @@ LRT_API lrt_status lrt_film_develop(lrt_scene *scene, const float *film_raw, flo
                                     int on_device);
 
 /* Test hook: per-lane radiance of wavefront lanes [lane_begin, lane_begin+n)
- * of the render described by opts, without film accumulation.
- * out: n * 4 floats {R, G, B, valid}.  */
+ * of the render described by opts, without film accumulation (of its FIRST pass
+ * when `samples_per_pass` or the 2^32 - 1 limit splits the render: lanes then
+ * count spp_per_pass samples per pixel).  out: n * 4 floats {R, G, B, valid}.  */
 LRT_API lrt_status lrt_render_samples(lrt_scene *scene, const lrt_render_opts *opts,
                                       uint64_t lane_begin, uint32_t n, float *out);
 
