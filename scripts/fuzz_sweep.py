@@ -11,7 +11,8 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
     xml, integ = random_scene_xml(seed)
     try:
         sc = mi.load_string(xml); o = orc.OrcScene(sc)
-        n = 48 * 40 * min(16, sc.desc.samples_per_pass or 16)
+        h, w, _ = sc.film_shape()
+        n = w * h * min(sc.spp, sc.desc.samples_per_pass or sc.spp)
         g = sc.render_samples(0, n, seed=seed); c = o.render_samples(0, n, seed=seed)
         same = (g.view(np.uint32) == c.view(np.uint32)).all(axis=1)
         st = sc.stats()

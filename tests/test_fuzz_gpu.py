@@ -66,7 +66,15 @@ def random_scene_xml(seed):
     rf = pick("box", "gaussian", "tent")
     sampler = pick("independent", "independent", "ldsampler")
     alpha = pick("rgb", "rgba")
-    spass = pick(0, 0, 4, 8) if integrator != "prbvolpath" else 0           # multi-pass renders (samples_per_pass)
+    spp = pick(16, 16, 16, 16, 12, 7, 3, 1) if sampler != "ldsampler" else 16     # non-power-of-two counts take the division path
+    fw, fh = (48, 40) if r.random() < 0.6 else (int(r.integers(17, 70)), int(r.integers(9, 50)))
+    crop = ""
+    if r.random() < 0.25:
+        cw, ch = int(r.integers(1, fw + 1)), int(r.integers(1, fh + 1))
+        cx, cy = int(r.integers(0, fw - cw + 1)), int(r.integers(0, fh - ch + 1))
+        crop = (f'<integer name="crop_offset_x" value="{cx}"/><integer name="crop_offset_y" value="{cy}"/>'
+                f'<integer name="crop_width" value="{cw}"/><integer name="crop_height" value="{ch}"/>')
+    spass = pick(0, 0, 4, 8) if (integrator != "prbvolpath" and spp == 16) else 0   # multi-pass renders (samples_per_pass)
     spass_xml = f'<integer name="samples_per_pass" value="{spass}"/>' if spass else ""
     xml = f"""<scene version="3.0.0">
   <integrator type="{integrator}"><integer name="max_depth" value="{pick(-1, 3, 6, 12)}"/><integer name="rr_depth" value="{pick(1, 3, 5)}"/>
@@ -74,8 +82,8 @@ def random_scene_xml(seed):
   {''.join(media)}
   <sensor type="perspective"><float name="fov" value="{r.uniform(30, 60):.2f}"/>
     <transform name="to_world"><lookat origin="{r.uniform(2.5, 4):.3f}, {r.uniform(1, 3):.3f}, {r.uniform(2.5, 4.5):.3f}" target="0, 0, 0" up="0, 1, 0"/></transform>
-    <sampler type="{sampler}"><integer name="sample_count" value="16"/><integer name="seed" value="{int(r.integers(0, 5))}"/></sampler>
-    <film type="hdrfilm"><integer name="width" value="48"/><integer name="height" value="40"/><string name="pixel_format" value="{alpha}"/><rfilter type="{rf}"/></film>
+    <sampler type="{sampler}"><integer name="sample_count" value="{spp}"/><integer name="seed" value="{int(r.integers(0, 5))}"/></sampler>
+    <film type="hdrfilm"><integer name="width" value="{fw}"/><integer name="height" value="{fh}"/>{crop}<string name="pixel_format" value="{alpha}"/><rfilter type="{rf}"/></film>
     {sensor_medium}
   </sensor>
   {''.join(shapes)}
@@ -89,8 +97,9 @@ def test_random_scene_bit_exact(mi, orc, seed):
     xml, integrator = random_scene_xml(seed)
     sc = mi.load_string(xml)
     o = orc.OrcScene(sc)
-    spass = sc.desc.samples_per_pass or 16
-    assert_lanes_equal(sc, o, 0, 48 * 40 * min(16, spass), seed=seed)        # the per-lane hook addresses the lanes of one pass
+    h, w, _ = sc.film_shape()
+    per_pass = min(sc.spp, sc.desc.samples_per_pass or sc.spp)
+    assert_lanes_equal(sc, o, 0, w * h * per_pass, seed=seed)                # the per-lane hook addresses the lanes of one pass
     if integrator == "prbvolpath":                              # the adjoint too: gradients equal up to summation order
         h, w, c = sc.film_shape()
         grad = np.random.default_rng(seed).random((h, w, c)).astype(np.float32) / (h * w * c)
