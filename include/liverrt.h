@@ -49,7 +49,11 @@ typedef enum {
 } lrt_status;
 
 /* ---------------------------------------------------------------- enums */
-enum { LRT_INTEGRATOR_PATH = 0, LRT_INTEGRATOR_VOLPATH = 1, LRT_INTEGRATOR_PRBVOLPATH = 2 };
+enum { LRT_INTEGRATOR_PATH = 0, LRT_INTEGRATOR_VOLPATH = 1, LRT_INTEGRATOR_PRBVOLPATH = 2,
+       LRT_INTEGRATOR_BIOVOLPATH = 3,    /* src/integrators/biovolpath.cpp, JIT-variant lane semantics   */
+       LRT_INTEGRATOR_BIOVOLPATH06 = 4   /* src/integrators/biovolpath06.cpp, scalar semantics per lane   */ };
+/* medium plugins: src/media/homogeneous.cpp, liver.cpp, parenchyma.cpp, glissonCapsule.cpp (docs/BIO_TRANSPORT_SPEC.md) */
+enum { LRT_MEDIUM_HOMOGENEOUS = 0, LRT_MEDIUM_LIVER = 1, LRT_MEDIUM_PARENCHYMA = 2, LRT_MEDIUM_GLISSON = 3 };
 enum { LRT_BSDF_DIFFUSE = 0, LRT_BSDF_DIELECTRIC = 1, LRT_BSDF_BUMPMAP = 2, LRT_BSDF_NULL = 3 };
 enum { LRT_TEX_RGB = 0, LRT_TEX_CHECKERBOARD = 1, LRT_TEX_BITMAP = 2 };
 enum { LRT_PHASE_ISOTROPIC = 0, LRT_PHASE_HG = 1 };
@@ -106,6 +110,15 @@ typedef struct {
     int32_t phase;            /* LRT_PHASE_*                                       */
     float   g;
     char    id[64];           /* XML id, used to form parameter keys               */
+    /* --- bio media (fork): element-competition sampling of the 5-argument Medium::sample_interaction,
+       used by the biovolpath integrators only; path / volpath / prbvolpath see the fields above.      */
+    int32_t type;             /* LRT_MEDIUM_*                                      */
+    float   layer_limit[4];   /* liver / glissonCapsule: layer1Limit..layer4Limit (liver.cpp:143-146)     */
+    float   sigma_collagen[4][3];  /* per layer, in the channel order the medium STORES them: the plugins read
+                                 G from "..._B" and B from "..._G" (liver.cpp:148-166)                    */
+    float   sigma_elastin[4][3];   /* layers 1-2 swapped the same way, layers 3-4 not (liver.cpp:168-186) */
+    float   sigma_blood[3], sigma_bile[3], sigma_lipid_water[3];   /* liver / parenchyma                 */
+    float   sigma_hepatocity;
 } lrt_medium_desc;
 
 typedef struct {

@@ -114,6 +114,7 @@ def cornell_box():
 # ------------------------------------------------------------- dict -> XML
 _TAGS = {
     "scene": "scene", "path": "integrator", "volpath": "integrator", "prbvolpath": "integrator",
+    "biovolpath": "integrator", "biovolpath06": "integrator",
     "perspective": "sensor", "independent": "sampler", "ldsampler": "sampler", "hdrfilm": "film",
     "box": "rfilter", "gaussian": "rfilter", "tent": "rfilter",
     "diffuse": "bsdf", "dielectric": "bsdf", "bumpmap": "bsdf", "null": "bsdf",

@@ -11,7 +11,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LRT_LIBRARY") or os.path.join(_HERE, "libliverrt.so")     # LRT_LIBRARY: developer builds (csrc/Makefile: exp)
 
 OK = 0
-INTEGRATOR = {"path": 0, "volpath": 1, "prbvolpath": 2}
+INTEGRATOR = {"path": 0, "volpath": 1, "prbvolpath": 2, "biovolpath": 3, "biovolpath06": 4}
+MEDIUM = {"homogeneous": 0, "liver": 1, "parenchyma": 2, "glissonCapsule": 3}
 
 
 class ShapeDesc(C.Structure):
@@ -34,7 +35,11 @@ class BsdfDesc(C.Structure):
 class MediumDesc(C.Structure):
     _fields_ = [("sigma_t", C.c_float * 3), ("albedo", C.c_float * 3), ("scale", C.c_float),
                 ("has_spectral_extinction", C.c_int32), ("sample_emitters", C.c_int32), ("phase", C.c_int32),
-                ("g", C.c_float), ("id", C.c_char * 64)]
+                ("g", C.c_float), ("id", C.c_char * 64),
+                # bio media (liver / parenchyma / glissonCapsule): include/liverrt.h
+                ("type", C.c_int32), ("layer_limit", C.c_float * 4), ("sigma_collagen", (C.c_float * 3) * 4),
+                ("sigma_elastin", (C.c_float * 3) * 4), ("sigma_blood", C.c_float * 3), ("sigma_bile", C.c_float * 3),
+                ("sigma_lipid_water", C.c_float * 3), ("sigma_hepatocity", C.c_float)]
 
 
 class EmitterDesc(C.Structure):

@@ -45,6 +45,7 @@ struct DeviceScene {
     uint32_t *pixel_list = nullptr; uint32_t pixel_list_rank = 0xffffffffu, pixel_list_count = 0, n_owned_pixels = 0;
     std::vector<hipEvent_t> ev_pool;
     std::vector<DMedium> h_media; DMedium *d_media = nullptr;
+    std::vector<DBioMedium> h_bio; DBioMedium *d_bio = nullptr;
     DLdsInfo lds{}; bool use_lds = false; int n_cus = 256;
 
     template <typename T> T *track(T *p) { allocs.push_back((void *) p); return p; }
@@ -155,7 +156,26 @@ static void build_hierarchy(const std::vector<float> &lum, uint32_t w, uint32_t 
     for (size_t i = 0; i < lv.size(); ++i) { E.level_offset[i] = lv[i].off; E.level_width[i] = lv[i].w; }
 }
 
+// log10 of the hepatocyte coefficient with the device's own arithmetic (liver.cpp:376 `dr::log2(att + 1) / dr::log2(10)`)
+__global__ void k_bio_prepare(DBioMedium *bio, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) bio[i].log10_hep = m_log2(bio[i].hepatocity + 1.f) / m_log2(10.f);
+}
+
 static void upload_media(DeviceScene *D, const lrt_scene_desc &d) {
+    D->h_bio.assign(std::max<uint32_t>(d.n_media, 1), DBioMedium{});
+    for (uint32_t i = 0; i < d.n_media; ++i) {
+        const lrt_medium_desc &M = d.media[i]; DBioMedium &o = D->h_bio[i];
+        o.type = M.type; o.has_spectral_extinction = M.has_spectral_extinction;
+        for (int l = 0; l < 4; ++l) { o.layer_limit[l] = M.layer_limit[l]; for (int k = 0; k < 3; ++k) { o.collagen[l][k] = M.sigma_collagen[l][k]; o.elastin[l][k] = M.sigma_elastin[l][k]; } }
+        for (int k = 0; k < 3; ++k) { o.blood[k] = M.sigma_blood[k]; o.bile[k] = M.sigma_bile[k]; o.lipid_water[k] = M.sigma_lipid_water[k]; }
+        o.hepatocity = M.sigma_hepatocity; o.log10_hep = 0.f;
+        if (M.type == LRT_MEDIUM_PARENCHYMA) { o.sigmat[0] = 77.2f / 255; o.sigmat[1] = 105.0f / 255; o.sigmat[2] = 149.0f / 255; }   // parenchyma.cpp:165
+        else for (int k = 0; k < 3; ++k) o.sigmat[k] = M.sigma_t[k] * M.scale;                                                       // liver.cpp:204-209
+    }
+    HIP_CHECK(hipMemcpyAsync(D->d_bio, D->h_bio.data(), D->h_bio.size() * sizeof(DBioMedium), hipMemcpyHostToDevice, D->stream));
+    k_bio_prepare<<<1, 64, 0, D->stream>>>(D->d_bio, (uint32_t) std::min<size_t>(D->h_bio.size(), 64));
+    HIP_CHECK(hipGetLastError());
     D->h_media.resize(std::max<uint32_t>(d.n_media, 1));
     for (uint32_t i = 0; i < d.n_media; ++i) {
         const lrt_medium_desc &M = d.media[i]; DMedium &o = D->h_media[i];
@@ -212,6 +232,8 @@ DeviceScene *device_scene_create(const lrt_scene_desc &d, int device) {
             #define LRT_SMEM(K) HIP_CHECK(hipFuncSetAttribute((const void *) K, hipFuncAttributeMaxDynamicSharedMemorySize, (int) total))
             LRT_SMEM((k_render<LRT_INTEGRATOR_PATH, 1024, true, false>)); LRT_SMEM((k_render<LRT_INTEGRATOR_VOLPATH, 1024, true, false>));
             LRT_SMEM((k_render<LRT_INTEGRATOR_PATH, 1024, true, true>)); LRT_SMEM((k_render<LRT_INTEGRATOR_VOLPATH, 1024, true, true>));
+            LRT_SMEM((k_render<LRT_INTEGRATOR_BIOVOLPATH, 1024, true, false>)); LRT_SMEM((k_render<LRT_INTEGRATOR_BIOVOLPATH, 1024, true, true>));
+            LRT_SMEM((k_render<LRT_INTEGRATOR_BIOVOLPATH06, 1024, true, false>)); LRT_SMEM((k_render<LRT_INTEGRATOR_BIOVOLPATH06, 1024, true, true>));
             LRT_SMEM((k_render_prb<false, 1024, true, false>)); LRT_SMEM((k_render_prb<true, 1024, true, false>));
             LRT_SMEM((k_render_prb<false, 1024, true, true>)); LRT_SMEM((k_render_prb<true, 1024, true, true>));
             LRT_SMEM((k_trace_lds<true>)); LRT_SMEM((k_trace_lds<false>));
@@ -283,7 +305,9 @@ DeviceScene *device_scene_create(const lrt_scene_desc &d, int device) {
     sc.bsdfs = D->track(dev_upload(bsdfs.data(), bsdfs.size(), st));
     // ---- media
     HIP_CHECK(hipMalloc((void **) &D->d_media, std::max<uint32_t>(d.n_media, 1) * sizeof(DMedium))); D->track(D->d_media);
-    upload_media(D.get(), d); sc.media = D->d_media;
+    HIP_CHECK(hipMalloc((void **) &D->d_bio, std::max<uint32_t>(d.n_media, 1) * sizeof(DBioMedium))); D->track(D->d_bio);
+    if (d.n_media > 64) throw std::runtime_error("at most 64 media are supported");
+    upload_media(D.get(), d); sc.media = D->d_media; sc.bio = D->d_bio;
     // ---- bounds (src/render/scene.cpp:49; include/mitsuba/core/bbox.h:343-346; envmap.cpp:337-351)
     DEnv &E = sc.env; memset(&E, 0, sizeof(E)); E.type = -1; E.emitter = -1;
     {
@@ -359,13 +383,14 @@ void device_scene_update_params(DeviceScene *D, const lrt_scene_desc &d) {
 static void ensure_workspace(DeviceScene *D, uint32_t capacity) {
     if (D->capacity >= capacity) return;
     auto alloc_q = [&](DPathStreams &q) {
-        D->release(q.o_maxt); D->release(q.d_eta); D->release(q.tp_pdf); D->release(q.res_flags); D->release(q.lp_lane); D->release(q.rng);
+        D->release(q.o_maxt); D->release(q.d_eta); D->release(q.tp_pdf); D->release(q.res_flags); D->release(q.lp_lane); D->release(q.rng); D->release(q.tdepth);
         HIP_CHECK(hipMalloc((void **) &q.o_maxt, (size_t) capacity * 16)); D->track(q.o_maxt);
         HIP_CHECK(hipMalloc((void **) &q.d_eta, (size_t) capacity * 16)); D->track(q.d_eta);
         HIP_CHECK(hipMalloc((void **) &q.tp_pdf, (size_t) capacity * 16)); D->track(q.tp_pdf);
         HIP_CHECK(hipMalloc((void **) &q.res_flags, (size_t) capacity * 16)); D->track(q.res_flags);
         HIP_CHECK(hipMalloc((void **) &q.lp_lane, (size_t) capacity * 16)); D->track(q.lp_lane);
         HIP_CHECK(hipMalloc((void **) &q.rng, (size_t) capacity * 8)); D->track(q.rng);
+        HIP_CHECK(hipMalloc((void **) &q.tdepth, (size_t) capacity * 4)); D->track(q.tdepth);
     };
     HIP_CHECK(hipStreamSynchronize(D->stream));
     alloc_q(D->q[0]); alloc_q(D->q[1]);
@@ -441,7 +466,10 @@ static DRenderParams make_params(const lrt_scene_desc &d, const ResolvedOpts &O,
     DRenderParams rp{};
     rp.integrator = O.integrator; rp.max_depth = O.max_depth; rp.rr_depth = O.rr_depth; rp.hide_emitters = O.hide_emitters;
     rp.spp = O.spp; rp.log2_spp = ((O.spp & (O.spp - 1)) == 0) ? (uint32_t) __builtin_ctz(O.spp) : 0xffffffffu;
-    rp.profile = (getenv("LRT_DEBUG_LAUNCH") ? 1u : 0u) | (getenv("LRT_EXP") ? (uint32_t) atoi(getenv("LRT_EXP")) : 0u);
+    rp.profile = getenv("LRT_DEBUG_LAUNCH") ? 1u : 0u;                 // bit 0: per-tile-kind timing, results unchanged
+#ifdef LRT_EXPERIMENT
+    if (getenv("LRT_EXP")) rp.profile |= (uint32_t) atoi(getenv("LRT_EXP"));   // cost-attribution switches (`make exp` build only)
+#endif
     rp.seed_value = d.sampler_seed + O.seed; rp.base_seed = d.sampler_seed; rp.seed = O.seed;
     rp.ld_count = d.sampler_type == LRT_SAMPLER_LD ? O.spp_total : 0u; rp.pass_index = O.pass; rp.spp_total = O.spp_total; rp.tile_rank = O.tile_rank; rp.tile_count = O.tile_count; rp.n_lanes = n_lanes;
     return rp;
@@ -516,15 +544,19 @@ static void run_wavefront(DeviceScene *D, const lrt_scene_desc &d, const Resolve
     HIP_CHECK(hipEventRecord(e_begin, st));
     // path.cpp:103-104 returns before the loop when max_depth == 0: that launch only retires the lanes
     const bool count_iter = !(O.integrator == LRT_INTEGRATOR_PATH && O.max_depth == 0);
-    const bool isp = O.integrator == LRT_INTEGRATOR_PATH;
     hipEvent_t a = get_event(D, log.ev++), b = get_event(D, log.ev++);
     HIP_CHECK(hipEventRecord(a, st));
     if (prb) launch_prb<false>(D, rp, g, pixel_list, lane_begin, nullptr, nullptr, nullptr, film, sample_out);
     else {
         #define LRT_LAUNCH(I, BS, LDSB) do { if (rp.ld_count) k_render<I, BS, LDSB, true><<<g.n_wg, BS, g.smem, st>>>(D->sc, rp, D->lds, D->q[0], D->q[1], g.P, D->counters, pixel_list, lane_begin, film, sample_out, lane_begin); \
                                              else k_render<I, BS, LDSB, false><<<g.n_wg, BS, g.smem, st>>>(D->sc, rp, D->lds, D->q[0], D->q[1], g.P, D->counters, pixel_list, lane_begin, film, sample_out, lane_begin); } while (0)
-        if (D->use_lds) { if (isp) LRT_LAUNCH(LRT_INTEGRATOR_PATH, 1024, true); else LRT_LAUNCH(LRT_INTEGRATOR_VOLPATH, 1024, true); }
-        else { if (isp) LRT_LAUNCH(LRT_INTEGRATOR_PATH, LRT_BLOCK, false); else LRT_LAUNCH(LRT_INTEGRATOR_VOLPATH, LRT_BLOCK, false); }
+        #define LRT_LAUNCH_I(BS, LDSB) do { switch (O.integrator) { \
+            case LRT_INTEGRATOR_PATH: LRT_LAUNCH(LRT_INTEGRATOR_PATH, BS, LDSB); break; \
+            case LRT_INTEGRATOR_BIOVOLPATH: LRT_LAUNCH(LRT_INTEGRATOR_BIOVOLPATH, BS, LDSB); break; \
+            case LRT_INTEGRATOR_BIOVOLPATH06: LRT_LAUNCH(LRT_INTEGRATOR_BIOVOLPATH06, BS, LDSB); break; \
+            default: LRT_LAUNCH(LRT_INTEGRATOR_VOLPATH, BS, LDSB); } } while (0)
+        if (D->use_lds) LRT_LAUNCH_I(1024, true); else LRT_LAUNCH_I(LRT_BLOCK, false);
+        #undef LRT_LAUNCH_I
         #undef LRT_LAUNCH
         HIP_CHECK(hipGetLastError());
     }

@@ -31,6 +31,18 @@ struct DMedium {
     float scale; float pad;              // sigma_t = property * scale (needed by the PRB adjoint)
 };
 
+// bio media (liver / parenchyma / glissonCapsule): element coefficients of the 5-argument sample_interaction
+// (kernels_bio.h); kept apart from DMedium so that the path / volpath kernels' medium loads stay as they are
+struct DBioMedium {
+    int32_t type, has_spectral_extinction;    // LRT_MEDIUM_*
+    float layer_limit[4];
+    float collagen[4][3], elastin[4][3];      // per layer, channel order as the plugins store them
+    float blood[3], bile[3], lipid_water[3];
+    float hepatocity, log10_hep;              // log10_hep = log2(hepatocity + 1) / log2(10), filled by k_bio_prepare (device arithmetic)
+    float sigmat[3];                          // what get_majorant reports: sigma_t * scale, or parenchyma's constants
+    float pad;
+};
+
 struct DEmitter {
     int32_t type, shape; float radiance[3]; float scale;
     float n[3]; float inv_area;          // area: rectangle frame normal (flip applied), 1/area
@@ -89,7 +101,7 @@ struct DScene {
     // geometry attributes
     const float *positions, *normals, *texcoords;
     const uint32_t *faces, *face_shape;
-    const DShape *shapes; const DBsdf *bsdfs; const DTexture *textures; const DMedium *media; const DEmitter *emitters;
+    const DShape *shapes; const DBsdf *bsdfs; const DTexture *textures; const DMedium *media; const DBioMedium *bio; const DEmitter *emitters;
     const float *tex_data;
     const float4 *env_data;    // (w+1) x h RGBx
     const float *env_hier;
@@ -125,8 +137,10 @@ struct DPathStreams {
     float4 *res_flags;         // result rgb, packed flags (bits)
     float4 *lp_lane;           // last scatter position, lane id (bits)
     uint2  *rng;               // PCG32 state
+    float  *tdepth;            // biovolpath / biovolpath06 only: the loop state `tissueDepth`
 };
-#define LRT_STATE_BYTES 88     // bytes per path record across all streams
+#define LRT_STATE_BYTES 88     // bytes per path record across all streams (path / volpath)
+#define LRT_STATE_BYTES_BIO 92 // biovolpath*: + tissueDepth; the maxt slot carries the previous ray query's distance
 
 // flag word layout
 #define PF_DEPTH_MASK   0x0000ffffu
@@ -136,6 +150,9 @@ struct DPathStreams {
 #define PF_SPECULAR     (1u << 26)     // volpath specular_chain / path prev_bsdf_delta
 #define PF_VALID        (1u << 27)
 #define PF_NOHIT        (1u << 28)     // look-ahead proved that the next free-flight segment reaches no surface
+#define PF_BIO_SCATTERED (1u << 29)    // biovolpath06: scattered_chain
+#define PF_BIO_EMIT     (1u << 30)     // biovolpath06: type & 0x0001 (EmittedRadiance)
+#define PF_BIO_FULL     (1u << 31)     // biovolpath06: type & 0x0004 and type & 0x0008 (they only appear together)
 
 struct DCounters {             // device-resident queue / statistics words
     uint32_t pad[4];

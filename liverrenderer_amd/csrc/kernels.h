@@ -17,21 +17,28 @@ namespace lrt {
 
 struct PathState {
     V3 o, d, tp, res, lp; float maxt, eta, last_pdf; uint32_t flags, lane; uint64_t rng_state;
+    float tdepth, si_t;        // biovolpath / biovolpath06: `tissueDepth`, distance returned by the previous trip's ray query
 };
 
+// BIO: a queued path's ray always comes from spawn_ray (maxt = largest float), so its maxt slot carries si_t instead, and
+// the seventh stream holds tissueDepth (92 B records)
+template <bool BIO = false>
 DEV void load_state(const DPathStreams &q, uint32_t i, PathState &s) {
     float4 a = q.o_maxt[i], b = q.d_eta[i], c = q.tp_pdf[i], d = q.res_flags[i], e = q.lp_lane[i]; uint2 r = q.rng[i];
     s.o = V3(a.x, a.y, a.z); s.maxt = a.w; s.d = V3(b.x, b.y, b.z); s.eta = b.w;
     s.tp = V3(c.x, c.y, c.z); s.last_pdf = c.w; s.res = V3(d.x, d.y, d.z); s.flags = f2u(d.w);
     s.lp = V3(e.x, e.y, e.z); s.lane = f2u(e.w); s.rng_state = ((uint64_t) r.y << 32) | r.x;
+    if (BIO) { s.si_t = a.w; s.maxt = kLargest; s.tdepth = q.tdepth[i]; }
 }
+template <bool BIO = false>
 DEV void store_state(const DPathStreams &q, uint32_t i, const PathState &s) {
-    q.o_maxt[i] = make_float4(s.o.x, s.o.y, s.o.z, s.maxt);
+    q.o_maxt[i] = make_float4(s.o.x, s.o.y, s.o.z, BIO ? s.si_t : s.maxt);
     q.d_eta[i] = make_float4(s.d.x, s.d.y, s.d.z, s.eta);
     q.tp_pdf[i] = make_float4(s.tp.x, s.tp.y, s.tp.z, s.last_pdf);
     q.res_flags[i] = make_float4(s.res.x, s.res.y, s.res.z, u2f(s.flags));
     q.lp_lane[i] = make_float4(s.lp.x, s.lp.y, s.lp.z, u2f(s.lane));
     q.rng[i] = make_uint2((uint32_t) s.rng_state, (uint32_t) (s.rng_state >> 32));
+    if (BIO) q.tdepth[i] = s.tdepth;
 }
 
 // Sampler::seed in the JIT branch of SamplingIntegrator::render (integrator.cpp:308-311): independent: TEA4(base + seed,
@@ -119,6 +126,7 @@ DEV PathState generate_camera_path(const DScene &sc, const DRenderParams &rp, co
     Ray ray = camera_ray(sc, fma_(spx, sc.film.scale_x, sc.film.offset_x), fma_(spy, sc.film.scale_y, sc.film.offset_y));
     PathState s;
     s.o = ray.o; s.d = ray.d; s.maxt = ray.maxt; s.eta = 1.f; s.tp = V3(1.f); s.res = V3(0.f); s.lp = V3(0.f); s.last_pdf = 1.f; s.lane = lane;
+    s.tdepth = 0.f; s.si_t = kInf;                                                   // biovolpath.cpp:125,129: si = zeros (t = inf), tissueDepth = 0
     bool env_visible = !rp.hide_emitters && sc.env.type >= 0;
     uint32_t flags = env_visible ? PF_VALID : 0u;
     if (rp.integrator == LRT_INTEGRATOR_PATH) flags |= PF_SPECULAR;                 // prev_bsdf_delta = true
@@ -127,6 +135,7 @@ DEV PathState generate_camera_path(const DScene &sc, const DRenderParams &rp, co
         uint32_t channel = min((uint32_t) (rng.next() * 3.f), 2u);                   // volpath.cpp:117-121
         flags |= channel << PF_CHANNEL_SHIFT;
         flags |= (uint32_t) (sc.cam.medium + 1) << PF_MEDIUM_SHIFT;
+        if (rp.integrator == LRT_INTEGRATOR_BIOVOLPATH06) flags |= PF_BIO_EMIT | PF_BIO_FULL;     // biovolpath06.cpp:111 type = 127
     }
     s.flags = flags; s.rng_state = rng.state;
     return s;
@@ -207,10 +216,13 @@ DEV void finish_paths_wave(const DScene &sc, const DRenderParams &rp, float *__r
     float a = valid ? 1.f : 0.f;
     unsigned long long todo = __ballot(finishing);
     const uint32_t me = threadIdx.x & 63u;
-    if (rp.profile & 2u) return;
+#ifdef LRT_EXPERIMENT
+    if (rp.profile & 2u) return;                    // cost attribution: no film atomics at all (RESULT-CHANGING, `make exp` only)
     int rounds = 0;
+#endif
     while (todo) {
-        if ((rp.profile & 4u) && rounds++ >= 2) {
+#ifdef LRT_EXPERIMENT
+        if ((rp.profile & 4u) && rounds++ >= 2) {   // cost attribution: per-lane atomics after two leaders
             if (finishing && ((todo >> me) & 1ull)) {
                 float *p = film + (size_t) pixel * F.channels;
                 atomicAdd(p + 0, L.x); atomicAdd(p + 1, L.y); atomicAdd(p + 2, L.z);
@@ -218,6 +230,7 @@ DEV void finish_paths_wave(const DScene &sc, const DRenderParams &rp, float *__r
             }
             break;
         }
+#endif
         int leader = __ffsll((long long) todo) - 1;
         uint32_t key = __shfl(pixel, leader);
         bool mine = finishing && pixel == key;
@@ -591,6 +604,10 @@ DEV bool path_iteration(const DScene &sc, const DRenderParams &rp, PathState &s,
     return active;
 }
 
+} // namespace lrt
+#include "kernels_bio.h"
+namespace lrt {
+
 // ---- the render kernel.  ONE launch per lrt_render: every workgroup is persistent and owns a private pool of path records
 // in HBM (two queues of cap = 2P records, P = paths in flight per workgroup).  A round of a workgroup:
 //   1. top the pool up to P paths with fresh camera lanes, taken from the global lane ticket (one atomic per round);
@@ -606,10 +623,11 @@ DEV bool path_iteration(const DScene &sc, const DRenderParams &rp, PathState &s,
 // n_a + n_b + n_c <= P, so the regions never collide.  No cross-workgroup dependency exists besides the lane ticket and the
 // film atomics; every wave leaves its loops once the ticket is exhausted and its pool is empty.
 DEV DPathStreams offset_streams(const DPathStreams &q, size_t off) {
-    DPathStreams r; r.o_maxt = q.o_maxt + off; r.d_eta = q.d_eta + off; r.tp_pdf = q.tp_pdf + off; r.res_flags = q.res_flags + off; r.lp_lane = q.lp_lane + off; r.rng = q.rng + off;
+    DPathStreams r; r.o_maxt = q.o_maxt + off; r.d_eta = q.d_eta + off; r.tp_pdf = q.tp_pdf + off; r.res_flags = q.res_flags + off; r.lp_lane = q.lp_lane + off; r.rng = q.rng + off; r.tdepth = q.tdepth + off;
     return r;
 }
 
+template <bool BIO = false>
 DEV void retire_and_compact_wave(const DScene &sc, const DRenderParams &rp, bool had_path, bool alive, const PathState &s,
                                  float *__restrict__ film, float *__restrict__ sample_out, uint64_t sample_base,
                                  const DPathStreams &qout, uint32_t P, uint32_t *s_out /* LDS [3] */) {
@@ -627,7 +645,7 @@ DEV void retire_and_compact_wave(const DScene &sc, const DRenderParams &rp, bool
     if (alive) {
         const unsigned long long mine = region == 0 ? m0 : (region == 1 ? m1 : m2);
         const uint32_t slot = b + (uint32_t) __popcll(mine & ((1ull << lane_in_wave) - 1ull));
-        store_state(qout, region == 0 ? slot : (region == 1 ? P + slot : 2u * P - 1u - slot), s);
+        store_state<BIO>(qout, region == 0 ? slot : (region == 1 ? P + slot : 2u * P - 1u - slot), s);
     }
 }
 
@@ -640,6 +658,7 @@ k_render(DScene sc, DRenderParams rp, DLdsInfo li, DPathStreams q0, DPathStreams
     __shared__ uint32_t s_in[3], s_out[3], s_ticket, s_fresh;
     __shared__ unsigned long long s_fresh_base, s_prof[8];
     const uint32_t tid = threadIdx.x, lane_in_wave = tid & 63u;
+    constexpr bool BIO = INTEGRATOR == LRT_INTEGRATOR_BIOVOLPATH || INTEGRATOR == LRT_INTEGRATOR_BIOVOLPATH06;
     if (tid < 8) s_prof[tid] = 0;
     LdsScene L{};
     if (LDS_BVH) {
@@ -686,7 +705,7 @@ k_render(DScene sc, DRenderParams rp, DLdsInfo li, DPathStreams q0, DPathStreams
                 if (t < ta) { i = (t << 6) + lane_in_wave; had_path = i < n_a; }
                 else if (t < ta + tc) { i = ((t - ta) << 6) + lane_in_wave; had_path = i < n_c; i += P; }
                 else { i = ((t - ta - tc) << 6) + lane_in_wave; had_path = i < n_b; i = 2u * P - 1u - i; }
-                if (had_path) { load_state(qin, i, s); n_loaded += 1; }
+                if (had_path) { load_state<BIO>(qin, i, s); n_loaded += 1; }
             } else {
                 const uint32_t i = ((t - ta - tc - tb) << 6) + lane_in_wave;
                 had_path = i < fresh;
@@ -706,6 +725,8 @@ k_render(DScene sc, DRenderParams rp, DLdsInfo li, DPathStreams q0, DPathStreams
             if (had_path) {
                 SamplerT<LD> rng = lane_rng_resume<LD>(rp, s.lane, s.rng_state);
                 if (INTEGRATOR == LRT_INTEGRATOR_PATH) alive = LDS_BVH ? path_iteration(sc, rp, s, rng, tr_lds, n_shadow) : path_iteration(sc, rp, s, rng, tr_glb, n_shadow);
+                else if (INTEGRATOR == LRT_INTEGRATOR_BIOVOLPATH) alive = LDS_BVH ? biovolpath_iteration(sc, rp, s, rng, tr_lds, n_shadow) : biovolpath_iteration(sc, rp, s, rng, tr_glb, n_shadow);
+                else if (INTEGRATOR == LRT_INTEGRATOR_BIOVOLPATH06) alive = LDS_BVH ? biovolpath06_iteration(sc, rp, s, rng, tr_lds) : biovolpath06_iteration(sc, rp, s, rng, tr_glb);
                 else alive = LDS_BVH ? volpath_iteration(sc, rp, s, rng, tr_lds, n_shadow, n_extra) : volpath_iteration(sc, rp, s, rng, tr_glb, n_shadow, n_extra);
                 s.rng_state = rng.state;
                 n_trips += 1;
@@ -725,7 +746,7 @@ k_render(DScene sc, DRenderParams rp, DLdsInfo li, DPathStreams q0, DPathStreams
                 }
             }
 #endif
-            retire_and_compact_wave(sc, rp, had_path, alive, s, film, sample_out, sample_base, qout, P, s_out);
+            retire_and_compact_wave<BIO>(sc, rp, had_path, alive, s, film, sample_out, sample_base, qout, P, s_out);
             if ((rp.profile & 1u) && lane_in_wave == 0) {
                 const int region = t < ta ? 0 : (t < ta + tc ? 1 : (t < ta + tc + tb ? 2 : 3));
                 atomicAdd(&s_prof[region], wall_clock64() - t_begin); atomicAdd(&s_prof[4 + region], 1ull);

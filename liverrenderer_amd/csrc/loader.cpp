@@ -2,13 +2,14 @@
 //
 // Replaces, for the plugins the liver scenes and mi.cornell_box() use, the
 // reference's src/core/parser.cpp + Properties + PluginManager instantiation.
-// Supported plugins: integrator {path, volpath, prbvolpath}; sensor perspective;
+// Supported plugins: integrator {path, volpath, prbvolpath, biovolpath, biovolpath06}; sensor perspective;
 // sampler {independent, ldsampler}; film hdrfilm; rfilter {box,
 // gaussian, tent}; bsdf {diffuse, dielectric, bumpmap, null}; texture {bitmap,
 // checkerboard}; medium {homogeneous, liver, parenchyma, glissonCapsule} (the
-// bio media are read as the base-class homogeneous medium their 4-argument
-// sample_interaction() falls back to); phase {isotropic,
-// hg}; shape {obj, rectangle, cube}; emitter {area, envmap, constant}.
+// bio media carry both the homogeneous parameters that path / volpath /
+// prbvolpath see through the 4-argument sample_interaction() and the element
+// coefficients of the 5-argument one, docs/BIO_TRANSPORT_SPEC.md); phase
+// {isotropic, hg}; shape {obj, rectangle, cube}; emitter {area, envmap, constant}.
 #include "host_scene.h"
 #include "xml.h"
 #include "image_io.h"
@@ -146,13 +147,20 @@ struct Loader {
             while (*p && (isspace((unsigned char) *p) || *p == ',')) ++p;
             if (!*p) break;
             char *e; double v = strtod(p, &e);
-            if (e == p) throw std::runtime_error("could not parse number list \"" + s + "\"");
+            if (e == p || (*e && !isspace((unsigned char) *e) && *e != ',')) throw std::runtime_error("could not parse number list \"" + s + "\"");
             r.push_back(v); p = e;
         }
         return r;
     }
-    // parsed as float (string::strtof in the reference)
-    static float parse_f32(const std::string &s) { char *e; float v = strtof(s.c_str(), &e); if (e == s.c_str()) throw std::runtime_error("could not parse floating point value \"" + s + "\""); return v; }
+    // src/core/parser.cpp:627-638: string::stof<double> (the whole string must be a number, trailing blanks allowed:
+    // src/core/string.cpp:39-65), stored as double and narrowed when the plugin fetches a ScalarFloat
+    static float parse_f32(const std::string &s) {
+        char *e; double v = strtod(s.c_str(), &e);
+        bool ok = e != s.c_str();
+        for (const char *p = e; ok && *p; ++p) if (*p != ' ' && *p != '\t') ok = false;
+        if (!ok) throw std::runtime_error("could not parse floating point value \"" + s + "\"");
+        return (float) v;
+    }
 
     void vec3_attr(const XmlNode &n, double def, double out[3]) {
         if (n.has("value")) { auto v = parse_list(attr(n, "value")); if (v.size() == 1) out[0] = out[1] = out[2] = v[0]; else if (v.size() == 3) { out[0] = v[0]; out[1] = v[1]; out[2] = v[2]; } else fail("<" + n.tag + ">: expected 1 or 3 values"); return; }
@@ -335,18 +343,46 @@ struct Loader {
     int make_medium(const ObjP &o) {
         auto it = medium_ix.find(o.get()); if (it != medium_ix.end()) return it->second;
         lrt_medium_desc M{};
-        bool bio_no_spectral = (o->type == "parenchyma");
-        if (o->type != "homogeneous" && o->type != "liver" && o->type != "parenchyma" && o->type != "glissonCapsule")
-            fail("unsupported medium type \"" + o->type + "\"");
-        // src/media/homogeneous.cpp:112-119, src/media/liver.cpp:139-141,194, src/media/parenchyma.cpp:140-151
+        if (o->type == "homogeneous") M.type = LRT_MEDIUM_HOMOGENEOUS;
+        else if (o->type == "liver") M.type = LRT_MEDIUM_LIVER;
+        else if (o->type == "parenchyma") M.type = LRT_MEDIUM_PARENCHYMA;
+        else if (o->type == "glissonCapsule") M.type = LRT_MEDIUM_GLISSON;
+        else fail("unsupported medium type \"" + o->type + "\"");
+        const bool parenchyma = M.type == LRT_MEDIUM_PARENCHYMA;
+        // src/media/homogeneous.cpp:112-119, src/media/liver.cpp:139-141,193-194, src/media/parenchyma.cpp:140-151
         get_rgb(*o, "sigma_t", 1.f, M.sigma_t); get_rgb(*o, "albedo", .75f, M.albedo);
         M.scale = get_float(*o, "scale", 1.f);
-        M.has_spectral_extinction = get_bool(*o, "has_spectral_extinction", !bio_no_spectral);
-        M.sample_emitters = get_bool(*o, "sample_emitters", !bio_no_spectral);
+        M.has_spectral_extinction = get_bool(*o, "has_spectral_extinction", !parenchyma);
+        M.sample_emitters = get_bool(*o, "sample_emitters", !parenchyma);
         M.phase = LRT_PHASE_ISOTROPIC; M.g = 0.f;
         if (ObjP ph = child(*o, "phase")) {
             if (ph->type == "hg") { M.phase = LRT_PHASE_HG; M.g = get_float(*ph, "g", 0.8f); if (!(M.g > -1.f && M.g < 1.f)) fail("The asymmetry parameter must lie in the interval (-1, 1)!"); }
             else if (ph->type != "isotropic") fail("unsupported phase function \"" + ph->type + "\"");
+        }
+        // ---- bio parameters of the 5-argument sample_interaction (docs/BIO_TRANSPORT_SPEC.md section 2)
+        for (int l = 0; l < 4; ++l) for (int c = 0; c < 3; ++c) M.sigma_collagen[l][c] = M.sigma_elastin[l][c] = 1.f;
+        static const float limits[4] = { 0.0065f, 0.0072f, 0.0083f, 0.01f };
+        for (int l = 0; l < 4; ++l) M.layer_limit[l] = limits[l];
+        for (int c = 0; c < 3; ++c) M.sigma_blood[c] = M.sigma_bile[c] = M.sigma_lipid_water[c] = 1.f;
+        M.sigma_hepatocity = 1.f;
+        if (M.type == LRT_MEDIUM_LIVER || M.type == LRT_MEDIUM_GLISSON) {        // liver.cpp:143-186, glissonCapsule.cpp:143-186
+            for (int l = 0; l < 4; ++l) {
+                const std::string n = std::to_string(l + 1);
+                M.layer_limit[l] = get_float(*o, ("layer" + n + "Limit").c_str(), limits[l]);
+                // the members are filled R <- "_R", G <- "_B", B <- "_G"; elastin layers 3 and 4 read straight
+                const bool swap_e = l < 2;
+                M.sigma_collagen[l][0] = get_float(*o, ("sigma_collagen" + n + "_R").c_str(), 1.f);
+                M.sigma_collagen[l][1] = get_float(*o, ("sigma_collagen" + n + "_B").c_str(), 1.f);
+                M.sigma_collagen[l][2] = get_float(*o, ("sigma_collagen" + n + "_G").c_str(), 1.f);
+                M.sigma_elastin[l][0] = get_float(*o, ("sigma_elastin" + n + "_R").c_str(), 1.f);
+                M.sigma_elastin[l][1] = get_float(*o, ("sigma_elastin" + n + (swap_e ? "_B" : "_G")).c_str(), 1.f);
+                M.sigma_elastin[l][2] = get_float(*o, ("sigma_elastin" + n + (swap_e ? "_G" : "_B")).c_str(), 1.f);
+            }
+        }
+        if (M.type == LRT_MEDIUM_LIVER || M.type == LRT_MEDIUM_PARENCHYMA) {     // liver.cpp:188-191, parenchyma.cpp:144-147
+            get_rgb(*o, "sigma_blood", 1.f, M.sigma_blood); get_rgb(*o, "sigma_bile", 1.f, M.sigma_bile);
+            get_rgb(*o, "sigma_lipid_water", 1.f, M.sigma_lipid_water);
+            M.sigma_hepatocity = get_float(*o, "sigma_hepatocity", 1.f);
         }
         snprintf(M.id, sizeof(M.id), "%s", o->id.empty() ? ("medium" + std::to_string(S.media.size())).c_str() : o->id.c_str());
         S.media.push_back(M); int ix = (int) S.media.size() - 1; medium_ix[o.get()] = ix; return ix;
@@ -540,7 +576,9 @@ struct Loader {
         if (o->type == "path") I.type = LRT_INTEGRATOR_PATH;
         else if (o->type == "volpath") I.type = LRT_INTEGRATOR_VOLPATH;
         else if (o->type == "prbvolpath") I.type = LRT_INTEGRATOR_PRBVOLPATH;
-        else fail("unsupported integrator \"" + o->type + "\" (supported: path, volpath, prbvolpath; pass e.g. the define integrator=volpath)");
+        else if (o->type == "biovolpath") I.type = LRT_INTEGRATOR_BIOVOLPATH;
+        else if (o->type == "biovolpath06") I.type = LRT_INTEGRATOR_BIOVOLPATH06;
+        else fail("unsupported integrator \"" + o->type + "\" (supported: path, volpath, prbvolpath, biovolpath, biovolpath06)");
         // src/render/integrator.cpp:535-552
         I.max_depth = get_int(*o, "max_depth", -1); I.rr_depth = get_int(*o, "rr_depth", 5); I.hide_emitters = get_bool(*o, "hide_emitters", false);
         if (I.max_depth < 0 && I.max_depth != -1) fail("\"max_depth\" must be set to -1 (infinite) or a value >= 0");

@@ -38,6 +38,11 @@ orc_scene *orc_scene_create(const lrt_scene_desc *desc);
 void       orc_scene_free(orc_scene *s);
 const char *orc_last_error(void);
 
+/* Bio transport (biovolpath + liver / parenchyma / glissonCapsule): which reading of the reference's source the oracle
+ * follows (oracle/orc_bio.h): 0 = the JIT variants' lane semantics (llvm_ad_rgb / cuda_rgb; default, what hip_ad_rgb
+ * implements), 1 = scalar_rgb (the reference's CPU renders).  `biovolpath06` is scalar-only and ignores it. */
+void orc_scene_set_bio_reading(orc_scene *s, int scalar);
+
 /* Medium / phase parameter edits (mirror of lrt_param_set on the copied desc). */
 int orc_param_set(orc_scene *s, const char *key, const float *v, int n);
 
@@ -85,6 +90,8 @@ void  orc_envmap_sample(orc_scene *s, float u1, float u2, float ref[3], float d[
 float orc_envmap_pdf(orc_scene *s, const float d[3]);
 void  orc_envmap_eval(orc_scene *s, const float d[3], float rgb[3]);
 float orc_rfilter_eval(orc_scene *s, float x);
+void  orc_bio_sample_interaction(orc_scene *s, int medium, const float o[3], const float d[3], float maxt, float sample,
+                                 uint32_t channel, float depth, int jit, float out[9]);
 void  orc_sample_ray(orc_scene *s, float px, float py, float o[3], float d[3], float *maxt);
 
 #ifdef __cplusplus

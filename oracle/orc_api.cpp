@@ -46,6 +46,7 @@ extern "C" orc_scene *orc_scene_create(const lrt_scene_desc *desc) {
 }
 
 extern "C" void orc_scene_free(orc_scene *s) { delete s; }
+extern "C" void orc_scene_set_bio_reading(orc_scene *s, int scalar) { s->s.bio_scalar = scalar != 0; }
 
 /* keys: "<medium id>.sigma_t.value", ".albedo.value", ".scale", ".phase_function.g"
    (src/media/homogeneous.cpp:146-151, src/phase/hg.cpp:60-62) */

@@ -76,6 +76,38 @@ static inline float m_log(float x) {
     return z;
 }
 
+/* --------------------------------------------------------------- log2f (Cephes)
+   cephes/single/log2f.c: same reduction and polynomial as logf, then the fraction's logarithm is multiplied by
+   log2(e) in two parts (LOG2EA = log2(e) - 1) and the exponent added.  Used by the bio media only
+   (src/media/liver.cpp:332,376 `dr::log2(attIndex + 1.0f) / dr::log2(10.0f)`). */
+static inline float m_log2(float x) {
+    if (x <= 0.f) return x == 0.f ? -kInf : NAN;
+    if (x == kInf) return kInf;
+    uint32_t ix = f2u(x);
+    int e = (int) (ix >> 23) - 126;
+    float m = u2f((ix & 0x007fffffu) | 0x3f000000u);
+    if (m < 0.707106781186547524f) { e -= 1; m = m + m - 1.f; } else { m = m - 1.f; }
+    float z = m * m;
+    float y = 7.0376836292E-2f;
+    y = fmaf(y, m, -1.1514610310E-1f);
+    y = fmaf(y, m, 1.1676998740E-1f);
+    y = fmaf(y, m, -1.2420140846E-1f);
+    y = fmaf(y, m, 1.4249322787E-1f);
+    y = fmaf(y, m, -1.6668057665E-1f);
+    y = fmaf(y, m, 2.0000714765E-1f);
+    y = fmaf(y, m, -2.4999993993E-1f);
+    y = fmaf(y, m, 3.3333331174E-1f);
+    y = y * m * z;
+    y = fmaf(-0.5f, z, y);
+    const float LOG2EA = 0.44269504088896340735992f;
+    z = y * LOG2EA;
+    z = fmaf(m, LOG2EA, z);
+    z += y;
+    z += m;
+    z += (float) e;
+    return z;
+}
+
 /* ---------------------------------------------------------------- expf (Cephes) */
 static inline float m_exp(float x) {
     if (x > 88.f) return kInf;

@@ -514,11 +514,12 @@ static float phase_eval(const lrt_medium_desc &M, V3 wi, V3 wo) {
 /* ------------------------------------------------------------ integrators */
 struct Ctx {
     const Scene &S; Sampler smp; int max_depth, rr_depth; bool hide_emitters;
+    bool bio_jit = true;            /* bio transport: JIT-variant reading (orc_bio.h); false: scalar_rgb reading */
     uint64_t n_iter = 0, n_shadow = 0, n_shadow_needed = 0;
-    Ctx(const Scene &s) : S(s) {}
+    Ctx(const Scene &s) : S(s), bio_jit(!s.bio_scalar) {}
     float next() { return smp.next1(); }
     void next2(float *x, float *y) { smp.next2(x, y); }
-    void skip(uint32_t n) { smp.skip(n); }
+    void skip(uint32_t n) { if (bio_jit) smp.skip(n); }   /* scalar code only executes the calls it reaches */
 };
 
 static inline int target_medium(const lrt_shape_desc &sd, V3 d, V3 n) {   /* interaction.h:330-344 */
@@ -840,6 +841,8 @@ static void path_sample(Ctx &C, Ray ray, V3 *out, bool *out_valid) {
     *out = valid_ray ? result : V3(0.f); *out_valid = valid_ray;
 }
 
+#include "orc_bio.h"
+
 /* --------------------------------------------------- PRB (prbvolpath.py) */
 /* Gradient accumulators of one lane: d/d sigma_t[3] (w.r.t. the `sigma_t` property, i.e. before `scale`),
    d/d albedo[3], d/d g of medium 0..: the reference differentiates whatever parameters have gradients
@@ -1118,6 +1121,8 @@ static SampleOut render_lane(const Scene &S, const Opts &O, uint64_t lane, orc_s
     V3 L; bool valid;
     if (O.integrator == LRT_INTEGRATOR_PATH) path_sample(C, ray, &L, &valid);
     else if (O.integrator == LRT_INTEGRATOR_PRBVOLPATH) prb_sample(C, ray, false, V3(0.f), V3(0.f), &L, &valid, nullptr);
+    else if (O.integrator == LRT_INTEGRATOR_BIOVOLPATH) biovolpath_sample(C, ray, S.d.sensor.medium, &L, &valid);
+    else if (O.integrator == LRT_INTEGRATOR_BIOVOLPATH06) biovolpath06_sample(C, ray, S.d.sensor.medium, &L, &valid);
     else volpath_sample(C, ray, S.d.sensor.medium, &L, &valid);
     if (st) { st->n_iter += C.n_iter; st->n_shadow += C.n_shadow; st->n_shadow_needed += C.n_shadow_needed; st->n_samples += 1; }
     if (carry) carry[lane] = C.smp.rng.state;
@@ -1270,6 +1275,8 @@ extern "C" int orc_render_scalar(orc_scene *s, const lrt_render_opts *opts, int 
                                          fmaf(spy, 1.f / (float) H, -(float) F.crop_offset_y / (float) H));
                     V3 L; bool valid;
                     if (O.integrator == LRT_INTEGRATOR_PATH) path_sample(Cx, ray, &L, &valid);
+                    else if (O.integrator == LRT_INTEGRATOR_BIOVOLPATH) biovolpath_sample(Cx, ray, S.d.sensor.medium, &L, &valid);
+                    else if (O.integrator == LRT_INTEGRATOR_BIOVOLPATH06) biovolpath06_sample(Cx, ray, S.d.sensor.medium, &L, &valid);
                     else volpath_sample(Cx, ray, S.d.sensor.medium, &L, &valid);
                     bool box = F.rfilter == LRT_RFILTER_BOX;
                     local.push_back({ L.x, L.y, L.z, valid ? 1.f : 0.f, box ? posx : spx, box ? posy : spy });
@@ -1329,6 +1336,7 @@ extern "C" void orc_math_eval(int fn, const float *x, const float *y, uint32_t n
         case 2: m_sincos(x[i], &out[i], &out2[i]); break;
         case 3: out[i] = m_atan2(y[i], x[i]); break;
         case 4: out[i] = m_acos(x[i]); break;
+        case 5: out[i] = m_log2(x[i]); break;
     }
 }
 extern "C" void orc_hg_sample(float g, const float wi[3], float u1, float u2, float wo[3], float *pdf) {
@@ -1351,6 +1359,16 @@ extern "C" void orc_envmap_eval(orc_scene *s, const float d[3], float rgb[3]) {
     V3 v = emitter_eval_env(s->s, V3(d[0], d[1], d[2])); rgb[0] = v.x; rgb[1] = v.y; rgb[2] = v.z;
 }
 extern "C" float orc_rfilter_eval(orc_scene *s, float x) { return s->s.rfilter_eval(x); }
+/* bio media: out = { t, transmittance rgb, p xyz, bio type, candidate distance } of the 5-argument sample_interaction */
+extern "C" void orc_bio_sample_interaction(orc_scene *s, int medium, const float o[3], const float d[3], float maxt, float sample,
+                                           uint32_t channel, float depth, int jit, float out[9]) {
+    const lrt_medium_desc &M = s->s.media[medium];
+    Ray r; r.o = V3(o[0], o[1], o[2]); r.d = V3(d[0], d[1], d[2]); r.maxt = maxt;
+    BioMI m = bio_sample_interaction(M, r, sample, channel, depth, jit != 0);
+    int bt; float dist; bio_compute_distance(M, channel, sample, depth, &bt, &dist);
+    out[0] = m.t; out[1] = m.transmittance.x; out[2] = m.transmittance.y; out[3] = m.transmittance.z;
+    out[4] = m.p.x; out[5] = m.p.y; out[6] = m.p.z; out[7] = (float) bt; out[8] = dist;
+}
 extern "C" void orc_sample_ray(orc_scene *s, float px, float py, float o[3], float d[3], float *maxt) {
     Ray r = sample_ray(s->s, px, py); o[0] = r.o.x; o[1] = r.o.y; o[2] = r.o.z; d[0] = r.d.x; d[1] = r.d.y; d[2] = r.d.z; *maxt = r.maxt;
 }

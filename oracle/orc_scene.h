@@ -67,6 +67,7 @@ struct Scene {
     /* reconstruction filter */
     float rf_radius = 0.5f; float rf_coeff[10]; float rf_inv_radius = 1.f;
     bool has_null_bsdf = false;
+    bool bio_scalar = false;                  /* bio transport reading: false = JIT variants (default), true = scalar_rgb */
 
     void finalize();
     Hit intersect(const Ray &r, bool any_hit, bool brute) const;

@@ -22,9 +22,9 @@ if "C4" in which:
     sc = mi.load_file(os.path.join(ROOT, "scenes/Liver-MultiMesh/mitsuba3/scene.xml"), integrator="volpath", spp=256, res_width=1920, res_height=1080)
     r = timed("C4 Liver-MultiMesh 1920x1080 volpath 256 spp (1 GPU)", lambda s: sc.render(seed=s), 1920 * 1080 * 256); r.update(sc.stats()); print(json.dumps(r), flush=True)
 if "C5" in which:
-    sc = mi.load_file(os.path.join(ROOT, "scenes/Parenchyma/mitsuba3/scene.xml"), integrator="prbvolpath", spp=256, res_width=1920, res_height=1080)
+    sc = mi.load_file(os.path.join(ROOT, "scenes/Parenchyma/mitsuba3/scene_temp.xml"), integrator="prbvolpath", spp=256, res_width=1920, res_height=1080)
     h, w, c = sc.film_shape()
     g = np.full((h, w, c), 1.0 / (h * w * c), np.float32)
     r = timed("C5 Parenchyma 1920x1080 prbvolpath backward 256 spp (1 GPU, primal + adjoint)", lambda s: sc.render_backward(g, seed=s), 1920 * 1080 * 256, reps=1); r.update(sc.stats()); print(json.dumps(r), flush=True)
-    sc2 = mi.load_file(os.path.join(ROOT, "scenes/Parenchyma/mitsuba3/scene.xml"), integrator="volpath", spp=64, res_width=1920, res_height=1080)
+    sc2 = mi.load_file(os.path.join(ROOT, "scenes/Parenchyma/mitsuba3/scene_temp.xml"), integrator="volpath", spp=64, res_width=1920, res_height=1080)
     r = timed("Parenchyma 1920x1080 volpath 64 spp", lambda s: sc2.render(seed=s), 1920 * 1080 * 64); r.update(sc2.stats()); print(json.dumps(r), flush=True)

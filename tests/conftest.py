@@ -10,8 +10,8 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 SCENES = os.path.join(ROOT, "scenes")
 LIVER_XML = os.path.join(SCENES, "Liver-SingleMesh", "mitsuba3", "scene.xml")
-PARENCHYMA_XML = os.path.join(SCENES, "Parenchyma", "mitsuba3", "scene.xml")
-GLISSON_XML = os.path.join(SCENES, "GlissonCapsule", "mitsuba3", "scene.xml")
+PARENCHYMA_XML = os.path.join(SCENES, "Parenchyma", "mitsuba3", "scene_temp.xml")      # scene.xml is LiverRenderer.py's template ("360:0.2464" placeholders)
+GLISSON_XML = os.path.join(SCENES, "GlissonCapsule", "mitsuba3", "scene_temp.xml")
 REALTIME_XML = os.path.join(SCENES, "Liver-SingleMesh-Realtime", "mitsuba3", "scene.xml")
 MULTIMESH_XML = os.path.join(SCENES, "Liver-MultiMesh", "mitsuba3", "scene.xml")
 

@@ -72,6 +72,10 @@ def lib():
     L.orc_rfilter_eval.argtypes = [C.c_void_p, C.c_float]
     L.orc_rfilter_eval.restype = C.c_float
     L.orc_sample_ray.argtypes = [C.c_void_p, C.c_float, C.c_float, P(C.c_float), P(C.c_float), P(C.c_float)]
+    L.orc_scene_set_bio_reading.argtypes = [C.c_void_p, C.c_int]
+    L.orc_scene_set_bio_reading.restype = None
+    L.orc_bio_sample_interaction.argtypes = [C.c_void_p, C.c_int, P(C.c_float), P(C.c_float), C.c_float, C.c_float, C.c_uint32, C.c_float, C.c_int, P(C.c_float)]
+    L.orc_bio_sample_interaction.restype = None
     L.orc_last_error.restype = C.c_char_p
     _orc = L
     return L
@@ -100,6 +104,15 @@ class OrcScene:
                 self._L.orc_scene_free(self._h); self._h = C.c_void_p(None)
         except Exception:
             pass
+
+    def set_bio_reading(self, scalar):
+        """bio transport: False = the JIT variants' lane semantics (default), True = scalar_rgb (oracle/orc_bio.h)"""
+        self._L.orc_scene_set_bio_reading(self._h, int(bool(scalar)))
+
+    def bio_sample_interaction(self, medium, o, d, maxt, sample, channel, depth, jit=True):
+        o = np.asarray(o, np.float32); d = np.asarray(d, np.float32); out = np.zeros(9, np.float32)
+        self._L.orc_bio_sample_interaction(self._h, medium, _fp(o), _fp(d), maxt, sample, channel, depth, int(jit), _fp(out))
+        return {"t": out[0], "transmittance": out[1:4].copy(), "p": out[4:7].copy(), "bio_type": int(out[7]), "distance": out[8]}
 
     def param_set(self, key, value):
         v = np.atleast_1d(np.asarray(value, dtype=np.float32))

@@ -166,15 +166,32 @@ def test_exr_writer_roundtrip(mi, tmp_path):
 
 
 def test_other_scene_files_load(mi):
-    sp = mi.load_file(PARENCHYMA_XML, integrator="volpath"); p = sp.desc       # keep the scene alive: desc is a view
+    # Parenchyma / GlissonCapsule: scene.xml is the template LiverRenderer.py:81-288 fills in ("360:0.2464" placeholders the
+    # reference's own parser rejects, src/core/parser.cpp:708-732); scene_temp.xml is the file it hands to the renderer
+    sp = mi.load_file(PARENCHYMA_XML); p = sp.desc                               # keep the scene alive: desc is a view
+    assert p.integrator.type == 4 and p.media[0].type == 2                       # biovolpath06 + parenchyma, the file's own defaults
     assert p.media[0].has_spectral_extinction == 0 and p.media[0].sample_emitters == 0      # src/media/parenchyma.cpp:149-150
     assert p.film.rfilter == 2 and p.integrator.hide_emitters == 1 and p.emitters[0].type == 2
+    assert list(p.media[0].sigma_blood) == pytest.approx([0.009222149349928413, 0.41800069299908693, 0.49250375679773445])
+    assert p.media[0].sigma_hepatocity == pytest.approx(269.26180490217416)
+    assert (p.film.width, p.film.height, p.sample_count, p.integrator.max_depth) == (1920, 1080, 256, 12)
     assert p.bsdfs[p.shapes[0].bsdf].eta == pytest.approx(1.38)
     etas = sorted(p.bsdfs[i].eta for i in range(p.n_bsdfs) if p.bsdfs[i].type == 1)
     assert etas[-1] == pytest.approx(1.5046 / 1.000277)           # <bsdf type="dielectric"/>: bk7 / air (include/mitsuba/render/ior.h)
-    sg = mi.load_file(GLISSON_XML, integrator="volpath"); g = sg.desc          # src/media/glissonCapsule.cpp:142-144,196-197
-    assert g.media[0].has_spectral_extinction == 1 and g.media[0].sample_emitters == 1 and g.sampler_type == 1 and g.sample_count == 64
-    assert (g.film.width, g.film.height, g.film.rfilter) == (1280, 720, 2) and g.integrator.max_depth == 65
+    with pytest.raises(RuntimeError, match="could not parse"):
+        mi.load_file(PARENCHYMA_XML.replace("scene_temp.xml", "scene.xml"))
+    sg = mi.load_file(GLISSON_XML); g = sg.desc                                  # src/media/glissonCapsule.cpp:142-144,196-197
+    assert g.integrator.type == 4 and g.media[0].type == 3
+    assert g.media[0].has_spectral_extinction == 1 and g.media[0].sample_emitters == 1 and g.sampler_type == 1 and g.sample_count == 256
+    assert (g.film.width, g.film.height, g.film.rfilter) == (1920, 1080, 2) and g.integrator.max_depth == 12
+    # the plugins read G from "..._B" and B from "..._G" (collagen 1-4, elastin 1-2), elastin 3-4 straight (glissonCapsule.cpp:148-186)
+    assert list(g.media[0].sigma_collagen[0]) == pytest.approx([3.146124563777685, 1.5741115169422308, 2.2189004838302524])
+    assert list(g.media[0].sigma_elastin[1]) == pytest.approx([0.3938675027663073, 2.6550010088623375, 1.074963350341639])
+    assert list(g.media[0].sigma_elastin[2]) == pytest.approx([0.5293245804372595, 1.4446597406707737, 3.5680965939208136])
+    assert list(g.media[0].layer_limit) == pytest.approx([0.0065, 0.0072, 0.0083, 0.01])
+    sl = mi.load_file(LIVER_XML); l = sl.desc                                    # Liver-SingleMesh: biovolpath + liver medium
+    assert l.integrator.type == 3 and l.media[0].type == 1 and l.media[0].has_spectral_extinction == 1
+    assert list(l.media[0].sigma_lipid_water) == pytest.approx([0.004632281950333333, 0.00048109802439999993, 0.00106273247395])
     sr = mi.load_file(REALTIME_XML, integrator="volpath"); r = sr.desc          # same scene, rr_depth = max_depth, 1 spp at 1920x1080
     assert (r.film.width, r.film.height, r.sample_count, r.integrator.rr_depth, r.integrator.max_depth) == (1920, 1080, 1, 12, 12)
     sm = mi.load_file(MULTIMESH_XML, integrator="path"); m = sm.desc
@@ -183,7 +200,7 @@ def test_other_scene_files_load(mi):
 
 def test_xml_errors(mi):
     with pytest.raises(RuntimeError, match="unsupported integrator"):
-        mi.load_file(LIVER_XML)                                   # default integrator is the fork's biovolpath
+        mi.load_file(LIVER_XML, integrator="volpathmis")
     with pytest.raises(RuntimeError, match="cannot open"):
         mi.load_file("/nonexistent/scene.xml")
     with pytest.raises(RuntimeError, match="undefined parameter"):
