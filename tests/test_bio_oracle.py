@@ -1,0 +1,126 @@
+"""Pins of the oracle's bio transport (oracle/orc_bio.h, docs/BIO_TRANSPORT_SPEC.md): the reference holds no numeric
+fixture for `biovolpath` / `liver` / `parenchyma` / `glissonCapsule`, so the pins are (1) the reference's own committed
+scalar_rgb render of Liver-SingleMesh as a weak image golden, (2) closed forms of the element competition on top of the
+already pinned PCG32 stream and logarithm."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import LIVER_XML, PARENCHYMA_XML, GLISSON_XML, ROOT
+
+DEFAULT_STREAM = 0xda3e39cb94b95bdb
+
+
+def inner_floats(orc, sample, n):
+    """the inner generator of computeDistance: PCG32 seeded with the sample's bit pattern, default stream (liver.cpp:233-235)"""
+    bits = int(np.float32(sample).view(np.uint32))
+    out = np.zeros(n, np.uint32)
+    orc.lib().orc_pcg32_u32(bits, DEFAULT_STREAM, n, out.ctypes.data_as(C.POINTER(C.c_uint32)))
+    f = ((out >> np.uint32(9)) | np.uint32(0x3f800000)).view(np.float32) - np.float32(1)
+    return np.where(f == 0, np.float32(0.5), f)
+
+
+def mlog(orc, x):
+    return orc.math_eval(0, np.asarray(x, np.float32))[0]
+
+
+def test_liver_singlemesh_cpu_render_weak_golden(mi, orc):
+    """The reference's committed scalar_rgb render of Liver-SingleMesh (biovolpath + liver medium, 1920x1080, 128 spp) against
+    the oracle's render of the same scene.xml with its own defaults: silhouette, directly seen environment, and the mean colour
+    of the liver's interior, which is all in-tissue transport (observed: 0.1-0.3 % per channel at 256 spp).  Both readings of
+    the source give this image (docs/BIO_TRANSPORT_SPEC.md section 6).  Fixture: tests/golden/make_liver_singlemesh_cpu_small.py."""
+    from scipy.ndimage import binary_erosion
+    g = np.load(os.path.join(ROOT, "tests", "golden", "reference_liver_singlemesh_cpu_down8.npy")).astype(np.float64)
+    xml = open(LIVER_XML).read(); base = os.path.dirname(LIVER_XML)
+    kw = dict(base_dir=base, res_width=240, res_height=135)
+    sc = mi.load_string(xml, spp=64, **kw)
+    assert sc.desc.integrator.type == 3 and sc.desc.media[0].type == 1           # no override: biovolpath, liver
+    o = orc.OrcScene(sc)
+    img = o.render().astype(np.float64)[..., :3]
+    env_only = re.sub(r'<shape type="obj".*?</shape>', '', xml, flags=re.S)
+    E = np.clip(orc.OrcScene(mi.load_string(env_only, spp=4, **kw)).render().astype(np.float64)[..., :3], 0, 1)
+    mg, mo = np.abs(g - E).max(-1) > 0.08, np.abs(np.clip(img, 0, 1) - E).max(-1) > 0.08
+    assert (mg & mo).sum() / (mg | mo).sum() > 0.98
+    inner = binary_erosion(mg & mo, iterations=6)
+    assert inner.sum() > 10000
+    ours, ref = img[inner].mean(0), g[inner].mean(0)
+    assert np.allclose(ours, ref, rtol=0.02), (ours, ref)                          # 64 spp: ~0.5 % noise on the mean
+    bg = ~(mg | mo)
+    assert np.abs(g - np.clip(img, 0, 1))[bg].mean() < 2e-3
+    # the scalar reading gives the same lanes for this scene (plain ifs in liver.cpp, nothing accumulated before the clearing block)
+    a = o.render_samples(135 * 240 * 64 // 2, 4096)
+    o.set_bio_reading(True); b = o.render_samples(135 * 240 * 64 // 2, 4096); o.set_bio_reading(False)
+    assert (a.view(np.uint32) == b.view(np.uint32)).all()
+
+
+def test_compute_distance_closed_forms(mi, orc):
+    """Candidate distances from the inner generator's floats and the pinned logarithm; winner = smallest; layer cascade."""
+    sc = mi.load_file(GLISSON_XML, spp=4, res_width=32, res_height=18)
+    o = orc.OrcScene(sc); M = sc.desc.media[0]
+    for sample in (0.25, 0.7312345, 1e-3, 0.999):
+        r = inner_floats(orc, sample, 4)
+        lr = mlog(orc, r)
+        for channel in range(3):
+            for depth, layer in ((0.0, 3), (0.007, 3), (0.0099, 3), (0.0101, 4), (5.0, 4)):          # every depth <= layer4Limit: layer 3
+                m = o.bio_sample_interaction(0, (0, 0, 0), (0, 0, 1), np.inf, sample, channel, depth)
+                if layer == 4:
+                    assert np.isinf(m["distance"]) and np.isinf(m["t"]) and (m["transmittance"] == 1).all()
+                    continue
+                c = np.float32(M.sigma_collagen[layer][channel]); e = np.float32(M.sigma_elastin[layer][channel])
+                cand = [-(np.float32(1) / c) * lr[0], -(np.float32(1) / e) * lr[1]]
+                want = cand[0] if not (cand[1] < cand[0]) else cand[1]
+                assert m["distance"] == np.float32(want) and m["t"] == m["distance"] and m["bio_type"] == 1
+                onehot = np.eye(3, dtype=np.float32)[channel]
+                assert (m["transmittance"] == onehot).all() and m["p"][2] == m["t"]
+                m2 = o.bio_sample_interaction(0, (0, 0, 0), (0, 0, 1), float(want) * 0.5, sample, channel, depth)   # surface nearer
+                assert np.isinf(m2["t"]) and (m2["transmittance"] == 1).all()
+
+
+def test_parenchyma_elements_and_readings(mi, orc):
+    """blood / bile / lipid-water absorb, hepatocytes attenuate (absorb inside 0.0025): scalar reading; in the JIT reading
+    parenchyma's `else if` branches vanish: absorbers scatter with transmittance 1, the hepatocyte radius is not tested."""
+    sc = mi.load_file(PARENCHYMA_XML, spp=4, res_width=32, res_height=18)
+    o = orc.OrcScene(sc); M = sc.desc.media[0]
+    l2 = lambda x: orc.math_eval(5, np.asarray([x], np.float32))[0][0]
+    log10h = l2(np.float32(M.sigma_hepatocity) + np.float32(1)) / l2(10.0)
+    assert log10h == pytest.approx(np.log10(M.sigma_hepatocity + 1), rel=1e-6)
+    rng = np.random.default_rng(3)
+    seen = set()
+    for sample in rng.random(400).astype(np.float32):
+        r = inner_floats(orc, sample, 4); lr = mlog(orc, r)
+        for channel in range(3):
+            att = [M.sigma_blood[channel], M.sigma_bile[channel], M.sigma_lipid_water[channel]]
+            cand = [-(np.float32(1) / np.float32(a)) * lr[i] for i, a in enumerate(att)] + [-(np.float32(log10h) * lr[3])]
+            win = 0
+            for i in range(1, 4):
+                if cand[i] < cand[win]: win = i
+            ms = o.bio_sample_interaction(0, (1, 2, 3), (0, 1, 0), np.inf, float(sample), channel, 0.0, jit=False)
+            mj = o.bio_sample_interaction(0, (1, 2, 3), (0, 1, 0), np.inf, float(sample), channel, 0.0, jit=True)
+            assert ms["distance"] == np.float32(cand[win]) == mj["distance"]
+            assert ms["bio_type"] == (2 if win == 3 else 0)
+            absorbed = win != 3 or float(cand[win]) < 0.0025
+            onehot = np.eye(3, dtype=np.float32)[channel]
+            assert (ms["transmittance"] == (0 if absorbed else onehot)).all() and ms["t"] == ms["distance"]
+            assert (mj["transmittance"] == (1 if win != 3 else onehot)).all() and mj["t"] == mj["distance"]
+            seen.add((win != 3, channel))
+    assert len(seen) == 6                                           # both outcomes in every channel
+
+
+def test_competition_winner_statistics(mi, orc):
+    """Exponential candidates with rates lambda_i: P(i wins) = lambda_i / sum(lambda), winner distance ~ Exp(sum)."""
+    sc = mi.load_file(PARENCHYMA_XML, spp=4, res_width=32, res_height=18)
+    o = orc.OrcScene(sc); M = sc.desc.media[0]
+    channel = 1
+    rates = np.array([M.sigma_blood[channel], M.sigma_bile[channel], M.sigma_lipid_water[channel], 1.0 / np.log10(M.sigma_hepatocity + 1)])
+    n = 20000
+    samples = (np.arange(n) + 0.5) / n * 0.999
+    wins, dist = np.zeros(2), []
+    for s in samples.astype(np.float32):
+        m = o.bio_sample_interaction(0, (0, 0, 0), (0, 0, 1), np.inf, float(s), channel, 0.0, jit=False)
+        wins[0 if m["bio_type"] == 2 else 1] += 1; dist.append(m["distance"])
+    p_hep = rates[3] / rates.sum()
+    assert wins[0] / n == pytest.approx(p_hep, abs=4 * np.sqrt(p_hep * (1 - p_hep) / n))
+    assert np.mean(dist) == pytest.approx(1 / rates.sum(), rel=0.03)
