@@ -1,13 +1,19 @@
 #!/usr/bin/env python3
 """Benchmark of the hip_ad_rgb hot path on BASELINE.json's metric: Msamples/s at fixed spp.
 
-A "step" is one complete render of the workload (ray generation -> wavefront loop -> film ->
-develop, plus the RCCL film all-reduce when N > 1).  N = 1 workload: BASELINE config C3
-(scenes/Liver-SingleMesh, plain `volpath`, 1920x1080, 512 spp, max_depth 12).  For N > 1 the SAME
-image is sharded by 32x32 pixel tiles over the ranks (strong scaling) and the per-rank raw films are
-summed with one all-reduce before develop.
+A "step" is one complete render of the workload (ray generation -> persistent sample loop -> film -> develop, plus the RCCL
+film all-reduce when N > 1).  Default workload (`--config c3`): BASELINE config C3 = scenes/Liver-SingleMesh, plain
+`volpath`, 1920x1080, 512 spp, max_depth 12.  Other single-GPU workloads of BASELINE.json, each with its own roofline:
 
-Prints ONE JSON line on rank 0 (contract: see the task statement).
+  --config c3bio        the same scene file with its OWN defaults' integrator and medium (`biovolpath` + `liver`), the
+                        transport every published timing of the reference is quoted on
+  --config c2           mi.cornell_box() at 1080x1080, `path`, 256 spp (Gaussian filter)
+  --config c5           PRB adjoint d(mean image)/d(sigma_t, albedo, g) on the Parenchyma scene, 1920x1080, 256 spp
+                        (a step = primal + adjoint pass; medium read as homogeneous)
+  --config parenchyma   scenes/Parenchyma/mitsuba3/scene_temp.xml with its own defaults (`biovolpath06`, ld sampler, tent)
+
+For N > 1 the SAME image is sharded by 32x32 pixel tiles over the ranks (strong scaling) and the per-rank raw films are
+summed with one all-reduce before develop.  Prints ONE JSON line on rank 0 (contract: see the task statement).
 """
 import argparse
 import json
@@ -22,7 +28,23 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-STATE_BYTES = 88               # bytes of one path record across the SoA streams (csrc/device_types.h)
+SCENES = os.path.join(ROOT, "scenes")
+
+# bytes of one path record across the SoA streams (csrc/device_types.h); PRB carries one more float4 stream (delta_L)
+RECORD_BYTES = {"path": 88, "volpath": 88, "biovolpath": 92, "biovolpath06": 92, "prbvolpath": 104}
+KERNEL_ID = {"path": 0, "volpath": 1, "biovolpath": 3, "biovolpath06": 4}
+CONFIGS = {
+    "c3": dict(scene=os.path.join(SCENES, "Liver-SingleMesh", "mitsuba3", "scene.xml"), integrator="volpath", spp=512, width=1920, height=1080,
+               label="C3 Liver-SingleMesh {integrator} {w}x{h} {spp} spp max_depth 12 (homogeneous medium, isotropic phase, envmap)"),
+    "c3bio": dict(scene=os.path.join(SCENES, "Liver-SingleMesh", "mitsuba3", "scene.xml"), integrator=None, spp=512, width=1920, height=1080,
+                  label="C3-bio Liver-SingleMesh {integrator} (file defaults: liver medium) {w}x{h} {spp} spp max_depth 12"),
+    "c2": dict(scene="cornell_box", integrator="path", spp=256, width=1080, height=1080,
+               label="C2 cornell_box {integrator} {w}x{h} {spp} spp max_depth 8 (Gaussian filter)"),
+    "c5": dict(scene=os.path.join(SCENES, "Parenchyma", "mitsuba3", "scene_temp.xml"), integrator="prbvolpath", spp=256, width=1920, height=1080,
+               label="C5 Parenchyma {integrator} backward (primal + adjoint) {w}x{h} {spp} spp, ld sampler, tent filter"),
+    "parenchyma": dict(scene=os.path.join(SCENES, "Parenchyma", "mitsuba3", "scene_temp.xml"), integrator=None, spp=256, width=1920, height=1080,
+                       label="Parenchyma {integrator} (file defaults: parenchyma medium, ld sampler, tent) {w}x{h} {spp} spp max_depth 12"),
+}
 
 
 def parse():
@@ -30,11 +52,12 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=3)
     p.add_argument("--warmup", type=int, default=1)
-    p.add_argument("--spp", type=int, default=512)
-    p.add_argument("--width", type=int, default=1920)
-    p.add_argument("--height", type=int, default=1080)
-    p.add_argument("--scene", default=os.path.join(ROOT, "scenes", "Liver-SingleMesh", "mitsuba3", "scene.xml"))
-    p.add_argument("--integrator", default="volpath")
+    p.add_argument("--config", default="c3", choices=sorted(CONFIGS))
+    p.add_argument("--spp", type=int, default=0, help="override the config's samples per pixel")
+    p.add_argument("--width", type=int, default=0)
+    p.add_argument("--height", type=int, default=0)
+    p.add_argument("--scene", default=None, help="override the config's scene file")
+    p.add_argument("--integrator", default=None, help="override the config's integrator")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--backend", default="nccl", help="process-group backend; gloo allows a multi-rank rehearsal on a single GPU")
     p.add_argument("--cpu-spp", type=int, default=0, help="spp of the bounded CPU-baseline sample (0: calibrate to ~15 s)")
@@ -59,11 +82,28 @@ def usable_cores():
     return max(1, n)
 
 
+def load(mi, cfg, spp, w, h, integrator):
+    if cfg["scene"] == "cornell_box":
+        d = mi.cornell_box()
+        d["sensor"]["film"]["width"], d["sensor"]["film"]["height"] = w, h
+        d["sensor"]["sampler"]["sample_count"] = spp
+        if integrator: d["integrator"]["type"] = integrator
+        return mi.load_dict(d)
+    kw = dict(spp=spp, res_width=w, res_height=h)
+    if integrator: kw["integrator"] = integrator
+    return mi.load_file(cfg["scene"], **kw)
+
+
 def main():
     a = parse()
+    cfg = dict(CONFIGS[a.config])
+    if a.scene: cfg["scene"] = a.scene
+    spp, w, h = a.spp or cfg["spp"], a.width or cfg["width"], a.height or cfg["height"]
+    integrator_override = a.integrator or cfg["integrator"]
     import torch
     import liverrenderer_amd as mi
-    from liverrenderer_amd.distributed import render_distributed
+    from liverrenderer_amd import _lib
+    from liverrenderer_amd.distributed import render_distributed, reduce_gradients
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -82,20 +122,27 @@ def main():
         if a.backend == "nccl": dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else: dist.init_process_group(a.backend)
 
-    scene = mi.load_file(a.scene, integrator=a.integrator, spp=a.spp, res_width=a.width, res_height=a.height)
+    scene = load(mi, cfg, spp, w, h, integrator_override)
+    integrator = {v: k for k, v in _lib.INTEGRATOR.items()}[scene.desc.integrator.type]
+    spp = scene.spp                                             # the ld sampler rounds up to 4, 16, 64, 256, ...
     h, w, _ = scene.film_shape()
     C = scene.raw_channels()
-    n_samples = w * h * a.spp
+    n_samples = w * h * spp
+    backward = integrator == "prbvolpath"
+    grad = (np.ones((h, w, C - 1), np.float32) / (h * w * (C - 1))) if backward else None      # loss = mean(image)
 
     def step(seed):
+        if backward:                                            # common.py:625-783: primal pass + adjoint replay
+            g = scene.render_backward(grad, spp=spp, seed=seed, tile_rank=rank, tile_count=world, device=local_rank)
+            return reduce_gradients(g) if world > 1 else g
         if world > 1:
-            img, raw = render_distributed(scene, spp=a.spp, seed=seed)
+            img, raw = render_distributed(scene, spp=spp, seed=seed)
             return img
         dev = torch.device("cuda", local_rank)
         film = torch.zeros((h, w, C), dtype=torch.float32, device=dev)
         image = torch.empty((h, w, C - 1), dtype=torch.float32, device=dev)
         torch.cuda.synchronize()
-        scene.render_to_device(film.data_ptr(), image.data_ptr(), spp=a.spp, seed=seed, device=local_rank)
+        scene.render_to_device(film.data_ptr(), image.data_ptr(), spp=spp, seed=seed, device=local_rank)
         return image
 
     def fence():
@@ -110,7 +157,7 @@ def main():
     t0 = time.perf_counter()
     kern_ms = iters = shadows = launches = records = 0.0
     for i in range(a.steps):
-        img = step(i)
+        step(i)
         st = scene.stats()
         kern_ms += st["kernel_ms"]; iters += st["n_iter"]; shadows += st["n_shadow"]; launches += st["n_launches"]; records += st["n_records"]
     fence()
@@ -121,56 +168,78 @@ def main():
         dt = float(t.item())
     value = n_samples * a.steps / dt / 1e6
 
-    # ---- roofline of the dominant kernel (k_render: ONE launch per step), this rank's launch.  Algorithmic bytes per
-    # launch: every queued path record is written once and read once (88 B each way; fresh camera paths run their first
-    # trip in registers and loop trips the look-ahead retires early move no record, so n_records <= n_iter - n_samples),
-    # plus 4*C bytes per pixel of film.  Duration: HIP events around the launch on the library's stream (kernel_ms).
+    # ---- roofline of the dominant kernel (k_render / k_render_prb: persistent, ONE launch per pass), this rank's launches.
+    # Algorithmic bytes: every queued path record is written once and read once (RECORD_BYTES each way; fresh camera paths
+    # run their first trip in registers and trips the look-ahead retires early move no record), plus what the launch
+    # leaves for the film: 4*C bytes per pixel (box filter: in-kernel splat) or 16 B per lane (wide filters and PRB: per-lane
+    # radiance for the splat pass / the adjoint replay, which reads it back).  Duration: HIP events around the launches on the
+    # library's stream (kernel_ms).  BASELINE.md "Roofline accounting" states the same model.
     n_rank = st["n_samples"]
-    alg_bytes = 2.0 * STATE_BYTES * records + 4.0 * C * w * h * a.steps / max(world, 1)
+    rec_b = RECORD_BYTES[integrator]
+    box = scene.desc.film.rfilter == 0
+    if backward: out_bytes = 2.0 * 16.0 * n_rank * a.steps
+    elif box: out_bytes = 4.0 * C * w * h * a.steps / max(world, 1)
+    else: out_bytes = 16.0 * n_rank * a.steps
+    alg_bytes = 2.0 * rec_b * records + out_bytes
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+    workload = cfg["label"].format(integrator=integrator, w=w, h=h, spp=spp)
     # HBM traffic per launch from the PMC passes of the same workload (scripts/profile_bench.sh -> profiles/*traffic.json)
     traffic = None
-    workload = f"C3 Liver-SingleMesh {a.integrator} {w}x{h} {a.spp} spp max_depth 12 (homogeneous medium, isotropic phase, envmap)"
     for tf in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic*.json"))):
         try:
             tj = json.load(open(tf))
             if tj.get("workload") == workload and world == 1: traffic = tj["traffic_bytes_per_launch"]
         except Exception:
             pass
+    ld = scene.desc.sampler_type == 1
+    kname = ("lrt::k_render_prb<*, 1024, true, %s>" % str(ld).lower()) if backward else ("lrt::k_render<%d, 1024, true, %s>" % (KERNEL_ID[integrator], str(ld).lower()))
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                "kernel": "lrt::k_render<%d, 1024, true, false>" % (0 if a.integrator == "path" else 1),
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "kernel": kname,
                 "launches_per_step": launches / a.steps, "avg_launch_ms": kern_ms / max(launches, 1),
-                "alg_bytes_per_launch": alg_bytes / max(launches, 1), "iterations_per_sample": iters / (n_rank * a.steps),
-                "records_per_sample": records / (n_rank * a.steps)}
+                "alg_bytes_per_launch": alg_bytes / max(launches, 1), "record_bytes": rec_b,
+                "iterations_per_sample": iters / (n_rank * a.steps), "records_per_sample": records / (n_rank * a.steps),
+                "shadow_queries_per_sample": shadows / (n_rank * a.steps)}
 
+    data = "mi.cornell_box() dictionary" if cfg["scene"] == "cornell_box" else "reference scene files (scene xml, liver2.obj, tissue_n.png, cavidade_latitude.exr)"
     out = {"metric": "Msamples/s", "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": a.steps,
            "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
-           "vs_baseline": None, "dtype": "f32", "data": "reference scene files (scene.xml, liver2.obj, tissue_n.png, cavidade_latitude.exr)",
-           "config": {"workload": workload,
-                      "width": w, "height": h, "spp": a.spp, "samples_per_step": n_samples,
+           "vs_baseline": None, "dtype": "f32", "data": data,
+           "config": {"workload": workload, "width": w, "height": h, "spp": spp, "samples_per_step": n_samples,
+                      "timed_region": "lrt_render / lrt_render_backward entry to the developed image (gradients) in device memory; scene resident in HBM",
                       "parallelism": "1 GPU" if world == 1 else f"32x32 pixel tiles over {world} GPUs + RCCL film all-reduce"},
            "roofline": roofline}
 
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+    if rank == 0 and world == 1 and not backward:
+        # SURVEY.md 8d's form of the metric: lrt_render entry to the developed image AND raw film in host memory (PCIe included)
+        scene.render(spp=spp, seed=77, return_raw=True)
+        t1 = time.perf_counter()
+        for i in range(max(1, a.steps)): scene.render(spp=spp, seed=i, return_raw=True)
+        hdt = (time.perf_counter() - t1) / max(1, a.steps)
+        out["host_visible"] = {"value": round(n_samples / hdt / 1e6, 3), "unit": "Msamples/s", "ms_per_step": round(hdt * 1e3, 3),
+                               "note": "lrt_render with host output buffers: developed image + raw film copied over PCIe inside the call (SURVEY.md 8d t_render); reported beside `value`, never as it"}
+
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and not backward:
         # ---- CPU baseline: the oracle (our restatement of the reference's CPU path) on the host cores,
         # same scene/resolution at a reduced spp, and the GPU-vs-oracle RMSE at that spp (same seed).
         import orc
         cores = usable_cores()
         if a.cpu_spp <= 0:                       # calibrate on 1 spp so that the sample takes ~15 s of wall time
-            cs = mi.load_file(a.scene, integrator=a.integrator, spp=1, res_width=a.width, res_height=a.height)
-            t1 = time.perf_counter(); orc.OrcScene(cs).render(threads=cores, spp=1, seed=0); c1 = time.perf_counter() - t1
-            a.cpu_spp = int(min(a.spp, max(1, round(15.0 / max(c1, 1e-3)))))
-        cs = mi.load_file(a.scene, integrator=a.integrator, spp=a.cpu_spp, res_width=a.width, res_height=a.height)
+            cs = load(mi, cfg, 1, w, h, integrator_override)
+            c_spp1 = cs.spp
+            t1 = time.perf_counter(); orc.OrcScene(cs).render(threads=cores, seed=0); c1 = (time.perf_counter() - t1) / c_spp1
+            a.cpu_spp = int(min(spp, max(1, round(15.0 / max(c1, 1e-3)))))
+        cs = load(mi, cfg, a.cpu_spp, w, h, integrator_override)
+        cpu_spp = cs.spp
         o = orc.OrcScene(cs)
         t1 = time.perf_counter()
-        cimg = o.render(threads=cores, spp=a.cpu_spp, seed=0)
+        cimg = o.render(threads=cores, seed=0)
         ct = time.perf_counter() - t1
-        gimg = cs.render(spp=a.cpu_spp, seed=0)
+        gimg = cs.render(seed=0)
         rmse = float(np.sqrt(np.mean((gimg.astype(np.float64) - cimg.astype(np.float64)) ** 2)))
-        out["cpu_baseline"] = {"value": round(w * h * a.cpu_spp / ct / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
-                               "sample": f"same scene and resolution at {a.cpu_spp} spp ({w * h * a.cpu_spp} samples, {ct:.1f} s)"}
-        out["rmse_vs_oracle"] = {"value": rmse, "spp": a.cpu_spp, "tolerance": 1e-4,
+        out["cpu_baseline"] = {"value": round(w * h * cpu_spp / ct / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
+                               "sample": f"same scene and resolution at {cpu_spp} spp ({w * h * cpu_spp} samples, {ct:.1f} s)",
+                               "build": "oracle/liborc.so: g++ -O2 -mfma -ffp-contract=off, scalar C++ restatement with llvm_ad_rgb lane semantics, one std::thread per granted core"}
+        out["rmse_vs_oracle"] = {"value": rmse, "spp": cpu_spp, "tolerance": 1e-4,
                                  "note": "same seed: per-lane radiance is bit-identical, the film differs by float-atomic order only"}
     if rank == 0:
         print(json.dumps(out), flush=True)

@@ -195,6 +195,9 @@ typedef struct {
     uint32_t tile_rank, tile_count;
     int32_t  device;          /* HIP device ordinal                                */
     int32_t  output_on_device;/* film_raw / image are device pointers              */
+    int32_t  grad_medium;     /* lrt_render_backward: index (into media[]) of the medium whose sigma_t / albedo / g
+                                 the gradients refer to; -1: the sum over all media (one shared parameter set) */
+    int32_t  pad;
 } lrt_render_opts;
 
 typedef struct {
@@ -244,7 +247,8 @@ LRT_API lrt_status lrt_film_develop(lrt_scene *scene, const float *film_raw, flo
 LRT_API lrt_status lrt_render_samples(lrt_scene *scene, const lrt_render_opts *opts,
                                       uint64_t lane_begin, uint32_t n, float *out);
 
-/* PRB adjoint: d(sum(image * grad_image)) / d(sigma_t, albedo, g) of medium 0. */
+/* PRB adjoint: d(sum(image * grad_image)) / d(sigma_t, albedo, g) of medium opts->grad_medium (the reference
+ * differentiates whichever parameters have gradients enabled: one call per medium gives the same numbers). */
 LRT_API lrt_status lrt_render_backward(lrt_scene *scene, const lrt_render_opts *opts,
                                        const float *grad_image, lrt_param_grads *out);
 

@@ -278,7 +278,7 @@ class Scene:
     def render_backward(self, grad_image, **kw):
         g = np.ascontiguousarray(grad_image, dtype=np.float32)
         o = make_opts(kw.get("integrator"), kw.get("max_depth"), kw.get("rr_depth"), kw.get("hide_emitters"), kw.get("spp", 0),
-                      kw.get("seed", 0), kw.get("tile_rank", 0), kw.get("tile_count", 1), kw.get("device", 0))
+                      kw.get("seed", 0), kw.get("tile_rank", 0), kw.get("tile_count", 1), kw.get("device", 0), grad_medium=kw.get("medium", 0))
         out = _lib.ParamGrads()
         _lib.check(self._lib.lrt_render_backward(self._h, C.byref(o), g.ctypes.data, C.byref(out)))
         return {"sigma_t": np.array(out.d_sigma_t[:], dtype=np.float32), "albedo": np.array(out.d_albedo[:], dtype=np.float32),
@@ -337,6 +337,10 @@ class SceneParameters(dict):
                 self[k] = v
         for k in sorted(self._dirty):
             if k.endswith(".phase_function.g") and float(self[k][0]) == 0.0:
+                try:                                   # g = 0 is a value of an hg phase function; an isotropic one has no such key
+                    self._scene.param_set(k, self[k])
+                except RuntimeError as e:
+                    if "isotropic" not in str(e): raise
                 continue
             self._scene.param_set(k, self[k])
         self._dirty.clear()

@@ -77,7 +77,7 @@ class SceneDesc(C.Structure):
 class RenderOpts(C.Structure):
     _fields_ = [("integrator", C.c_int32), ("max_depth", C.c_int32), ("rr_depth", C.c_int32), ("hide_emitters", C.c_int32),
                 ("spp", C.c_uint32), ("seed", C.c_uint32), ("tile_rank", C.c_uint32), ("tile_count", C.c_uint32),
-                ("device", C.c_int32), ("output_on_device", C.c_int32)]
+                ("device", C.c_int32), ("output_on_device", C.c_int32), ("grad_medium", C.c_int32), ("pad", C.c_int32)]
 
 
 class RenderStats(C.Structure):
@@ -98,7 +98,7 @@ class HitsSoA(C.Structure):
 
 
 def make_opts(integrator=None, max_depth=None, rr_depth=None, hide_emitters=None, spp=0, seed=0,
-              tile_rank=0, tile_count=1, device=0, output_on_device=False):
+              tile_rank=0, tile_count=1, device=0, output_on_device=False, grad_medium=0):
     o = RenderOpts()
     o.integrator = -1 if integrator is None else (INTEGRATOR[integrator] if isinstance(integrator, str) else int(integrator))
     o.max_depth = -2 if max_depth is None else int(max_depth)
@@ -106,6 +106,7 @@ def make_opts(integrator=None, max_depth=None, rr_depth=None, hide_emitters=None
     o.hide_emitters = -1 if hide_emitters is None else int(bool(hide_emitters))
     o.spp, o.seed, o.tile_rank, o.tile_count = int(spp), int(seed) & 0xffffffff, int(tile_rank), int(tile_count)
     o.device, o.output_on_device = int(device), int(bool(output_on_device))
+    o.grad_medium = int(grad_medium)
     return o
 
 

@@ -28,7 +28,7 @@ static lrt_status fail(lrt_status st, const std::string &msg) { g_error = msg; r
 extern "C" {
 
 const char *lrt_last_error(void) { return g_error.c_str(); }
-int lrt_version(void) { return 101; }    // 1.1: sampler_type / samples_per_pass in lrt_scene_desc, n_records in lrt_render_stats, lrt_image_write_png
+int lrt_version(void) { return 102; }    // 1.2: bio media fields in lrt_medium_desc, biovolpath integrators, grad_medium in lrt_render_opts
 
 static std::vector<std::pair<std::string, std::string>> parse_defines(const char *const *defines, int n) {
     std::vector<std::pair<std::string, std::string>> r;
@@ -61,17 +61,74 @@ lrt_status lrt_scene_load_xml(const char *path, const char *const *defines, int 
     return lrt_scene_load_xml_string(ss.str().c_str(), dir.c_str(), defines, n_defines, out);
 }
 
+// Every index, range and pointer of a caller-built description (the XML loader's own output passes by construction).
+static void validate_desc(const lrt_scene_desc &d) {
+    auto bad = [](const std::string &m) { throw std::runtime_error("lrt_scene_from_desc: " + m); };
+    if ((d.n_vertices && (!d.positions || !d.normals || !d.texcoords)) || (d.n_faces && (!d.faces || !d.face_shape))) bad("null geometry array");
+    if ((d.n_shapes && !d.shapes) || (d.n_bsdfs && !d.bsdfs) || (d.n_textures && !d.textures) || (d.n_media && !d.media) || (d.n_emitters && !d.emitters)) bad("null object array");
+    for (uint32_t f = 0; f < 3 * d.n_faces; ++f) if (d.faces[f] >= d.n_vertices) bad("face references an invalid vertex");
+    for (uint32_t f = 0; f < d.n_faces; ++f) if (d.face_shape[f] >= d.n_shapes) bad("face references an invalid shape");
+    for (uint32_t i = 0; i < d.n_textures; ++i) {
+        const lrt_texture_desc &T = d.textures[i];
+        if (T.type < LRT_TEX_RGB || T.type > LRT_TEX_BITMAP) bad("invalid texture type");
+        if (T.type == LRT_TEX_BITMAP && (!T.data || T.width < 1 || T.height < 1 || (T.channels != 1 && T.channels != 3))) bad("bitmap texture without texels or with invalid dimensions");
+    }
+    for (uint32_t i = 0; i < d.n_bsdfs; ++i) {
+        const lrt_bsdf_desc &B = d.bsdfs[i];
+        if (B.type < LRT_BSDF_DIFFUSE || B.type > LRT_BSDF_NULL) bad("invalid bsdf type");
+        if (B.type == LRT_BSDF_DIFFUSE) {
+            if (B.reflectance < 0 || (uint32_t) B.reflectance >= d.n_textures) bad("diffuse bsdf references an invalid texture");
+            if (d.textures[B.reflectance].type == LRT_TEX_BITMAP) throw std::runtime_error("unsupported: a bitmap texture as diffuse reflectance (bitmaps are supported as bump-map heights only)");
+        }
+        if (B.type == LRT_BSDF_BUMPMAP) {
+            if (B.nested < 0 || (uint32_t) B.nested >= d.n_bsdfs || d.bsdfs[B.nested].type == LRT_BSDF_BUMPMAP) bad("bumpmap references an invalid nested bsdf");
+            if (B.texture < 0 || (uint32_t) B.texture >= d.n_textures) bad("bumpmap references an invalid texture");
+        }
+        if (B.type == LRT_BSDF_DIELECTRIC && !(B.eta > 0.f)) bad("dielectric with a non-positive relative index of refraction");
+    }
+    for (uint32_t i = 0; i < d.n_media; ++i) {
+        const lrt_medium_desc &M = d.media[i];
+        if (M.type < LRT_MEDIUM_HOMOGENEOUS || M.type > LRT_MEDIUM_GLISSON) bad("invalid medium type");
+        if (M.phase != LRT_PHASE_ISOTROPIC && M.phase != LRT_PHASE_HG) bad("invalid phase function");
+        if (M.phase == LRT_PHASE_HG && !(M.g > -1.f && M.g < 1.f)) bad("The asymmetry parameter must lie in the interval (-1, 1)!");
+    }
+    for (uint32_t i = 0; i < d.n_shapes; ++i) {
+        const lrt_shape_desc &s = d.shapes[i];
+        if (s.bsdf < 0 || (uint32_t) s.bsdf >= d.n_bsdfs) bad("shape references an invalid bsdf");
+        if (s.emitter < -1 || s.emitter >= (int) d.n_emitters || s.interior_medium < -1 || s.interior_medium >= (int) d.n_media || s.exterior_medium < -1 || s.exterior_medium >= (int) d.n_media)
+            bad("shape references an invalid emitter/medium");
+        if ((uint64_t) s.first_face + s.n_faces > d.n_faces) bad("shape face range exceeds the face array");
+        if (s.emitter >= 0 && (d.emitters[s.emitter].type != LRT_EMITTER_AREA || d.emitters[s.emitter].shape != (int) i)) bad("shape and area emitter do not reference each other");
+    }
+    uint32_t n_env = 0;
+    for (uint32_t i = 0; i < d.n_emitters; ++i) {
+        const lrt_emitter_desc &E = d.emitters[i];
+        if (E.type < LRT_EMITTER_AREA || E.type > LRT_EMITTER_CONSTANT) bad("invalid emitter type");
+        if (E.type == LRT_EMITTER_AREA) {
+            if (E.shape < 0 || (uint32_t) E.shape >= d.n_shapes) bad("area emitter references an invalid shape");
+            const lrt_shape_desc &s = d.shapes[E.shape];
+            if (s.kind != LRT_SHAPE_RECTANGLE || s.n_faces < 1) bad("area emitters are supported on rectangle shapes only");
+        } else ++n_env;
+        if (E.type == LRT_EMITTER_ENVMAP && (!E.data || E.width < 2 || E.height < 3)) bad("environment map without data or smaller than 2x3 pixels");
+    }
+    if (n_env > 1) bad("Only one environment emitter can be specified per scene.");
+    if (d.sensor.medium < -1 || d.sensor.medium >= (int) d.n_media) bad("sensor references an invalid medium");
+    if (!(d.sensor.near_clip > 0.f) || !(d.sensor.near_clip < d.sensor.far_clip)) bad("invalid clipping planes");
+    if (!(d.sensor.fov_x > 0.f && d.sensor.fov_x < 180.f)) bad("The horizontal field of view must be in the range [0, 180]!");
+    const lrt_film_desc &F = d.film;
+    if (F.width <= 0 || F.height <= 0 || F.crop_width <= 0 || F.crop_height <= 0 || F.crop_offset_x < 0 || F.crop_offset_y < 0 ||
+        F.crop_offset_x + F.crop_width > F.width || F.crop_offset_y + F.crop_height > F.height) bad("Invalid crop window specification!");
+    if (F.rfilter < LRT_RFILTER_BOX || F.rfilter > LRT_RFILTER_TENT || (F.rfilter != LRT_RFILTER_BOX && !(F.rfilter_param > 0.f))) bad("invalid reconstruction filter");
+    if (d.integrator.type < LRT_INTEGRATOR_PATH || d.integrator.type > LRT_INTEGRATOR_BIOVOLPATH06) bad("invalid integrator type");
+    if (d.integrator.max_depth < -1 || d.integrator.rr_depth <= 0) bad("invalid max_depth / rr_depth");
+    if (d.sampler_type > LRT_SAMPLER_LD || d.sample_count == 0) bad("invalid sampler");
+}
+
 lrt_status lrt_scene_from_desc(const lrt_scene_desc *desc, lrt_scene **out) {
     if (!desc || !out) return fail(LRT_ERR_INVALID, "lrt_scene_from_desc: null argument");
     *out = nullptr;
     LRT_TRY
-        for (uint32_t f = 0; f < 3 * desc->n_faces; ++f) if (desc->faces[f] >= desc->n_vertices) throw std::runtime_error("face references an invalid vertex");
-        for (uint32_t f = 0; f < desc->n_faces; ++f) if (desc->face_shape[f] >= desc->n_shapes) throw std::runtime_error("face references an invalid shape");
-        for (uint32_t i = 0; i < desc->n_shapes; ++i) {
-            const lrt_shape_desc &s = desc->shapes[i];
-            if (s.bsdf < 0 || (uint32_t) s.bsdf >= desc->n_bsdfs) throw std::runtime_error("shape references an invalid bsdf");
-            if (s.emitter >= (int) desc->n_emitters || s.interior_medium >= (int) desc->n_media || s.exterior_medium >= (int) desc->n_media) throw std::runtime_error("shape references an invalid emitter/medium");
-        }
+        validate_desc(*desc);
         std::unique_ptr<lrt_scene> s(new lrt_scene());
         s->st.copy_from(*desc);
         *out = s.release();
@@ -164,7 +221,11 @@ lrt_status lrt_param_set(lrt_scene *scene, const char *key, const float *v, int 
         for (int i = 0; i < 3; ++i) dst[i] = v[n == 3 ? i : 0];
     } else if (!strcmp(rest, "scale")) M->scale = v[0];
     else if (!strcmp(rest, "phase_function.g")) {
+        // mi.traverse exposes `g` for an hg phase function only (src/phase/hg.cpp:60-62; isotropic.cpp has no parameter).  The
+        // one extension kept from round 1: a NON-ZERO g on an isotropic medium turns it into hg ("HG variant ...
+        // supplied through lrt_param_set"); g = 0 on an isotropic medium is rejected like any unknown key.
         if (!(v[0] > -1.f && v[0] < 1.f)) return fail(LRT_ERR_INVALID, "The asymmetry parameter must lie in the interval (-1, 1)!");
+        if (M->phase != LRT_PHASE_HG && v[0] == 0.f) return fail(LRT_ERR_INVALID, std::string("unknown parameter \"") + key + "\" (the medium's phase function is isotropic)");
         M->g = v[0]; M->phase = LRT_PHASE_HG;
     } else return fail(LRT_ERR_INVALID, std::string("unknown parameter \"") + key + "\"");
     scene->params_dirty = true;

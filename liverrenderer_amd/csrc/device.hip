@@ -209,7 +209,10 @@ DeviceScene *device_scene_create(const lrt_scene_desc &d, int device) {
         const size_t n_nodes = bvh.nodes.size() / 16, n_slots = bvh.tris.size() / 12, n_verts = d.n_vertices;
         const size_t nodes_b = n_nodes * 64, verts_b = (n_verts * 16 + 15) & ~size_t(15), tris_b = (n_slots * 8 + 15) & ~size_t(15);
         const size_t stack_b = (size_t) 2 * LRT_LDS_STACK * 1024, total = nodes_b + verts_b + tris_b + stack_b;
-        const size_t lds_limit = std::min<size_t>((size_t) prop.sharedMemPerBlock ? 160 * 1024 : 64 * 1024, 160 * 1024) - 512;
+        // LDS a workgroup may ask for: the device's opt-in maximum (160 KiB on gfx950), minus the kernel's static __shared__ words
+        int optin = 0; if (hipDeviceGetAttribute(&optin, hipDeviceAttributeSharedMemPerBlockOptin, device) != hipSuccess || optin <= 0) optin = (int) prop.sharedMemPerBlock;
+        (void) hipGetLastError();
+        const size_t lds_limit = std::min<size_t>((size_t) std::max(optin, 0), 160 * 1024) - 512;
         if (d.n_faces > 0 && n_verts <= 65535 && n_nodes <= 32767 && n_slots <= 32767 && bvh.max_depth < LRT_LDS_STACK && total <= lds_limit && !getenv("LRT_NO_LDS_BVH")) {
             std::vector<unsigned char> blob(nodes_b + verts_b + tris_b, 0);
             memcpy(blob.data(), bvh.nodes.data(), nodes_b);
@@ -229,7 +232,7 @@ DeviceScene *device_scene_create(const lrt_scene_desc &d, int device) {
             D->lds.slot_prim = D->track(dev_upload(slot_prim.data(), slot_prim.size(), st));
             D->lds.blob_bytes = (uint32_t) blob.size(); D->lds.nodes_off = 0; D->lds.verts_off = (uint32_t) nodes_b; D->lds.tris_off = (uint32_t) (nodes_b + verts_b);
             D->lds.stack_off = (uint32_t) blob.size(); D->lds.total_bytes = (uint32_t) total;
-            #define LRT_SMEM(K) HIP_CHECK(hipFuncSetAttribute((const void *) K, hipFuncAttributeMaxDynamicSharedMemorySize, (int) total))
+            #define LRT_SMEM(K) HIP_CHECK(hipFuncSetAttribute((const void *) K, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_limit))
             LRT_SMEM((k_render<LRT_INTEGRATOR_PATH, 1024, true, false>)); LRT_SMEM((k_render<LRT_INTEGRATOR_VOLPATH, 1024, true, false>));
             LRT_SMEM((k_render<LRT_INTEGRATOR_PATH, 1024, true, true>)); LRT_SMEM((k_render<LRT_INTEGRATOR_VOLPATH, 1024, true, true>));
             LRT_SMEM((k_render<LRT_INTEGRATOR_BIOVOLPATH, 1024, true, false>)); LRT_SMEM((k_render<LRT_INTEGRATOR_BIOVOLPATH, 1024, true, true>));
@@ -300,6 +303,8 @@ DeviceScene *device_scene_create(const lrt_scene_desc &d, int device) {
             if (B.nested < 0 || (uint32_t) B.nested >= d.n_bsdfs || d.bsdfs[B.nested].type == LRT_BSDF_BUMPMAP) throw std::runtime_error("bumpmap: invalid nested BSDF");
             bsdfs[i].flags = leaf_flags(d.bsdfs[B.nested].type);
         } else bsdfs[i].flags = leaf_flags(B.type);
+        if (B.type == LRT_BSDF_DIFFUSE && (B.reflectance < 0 || (uint32_t) B.reflectance >= d.n_textures || d.textures[B.reflectance].type == LRT_TEX_BITMAP))
+            throw std::runtime_error("unsupported: a bitmap texture as diffuse reflectance (bitmaps are supported as bump-map heights only)");
         if (B.type == LRT_BSDF_NULL) sc.has_null_bsdf = 1;
     }
     sc.bsdfs = D->track(dev_upload(bsdfs.data(), bsdfs.size(), st));
@@ -445,6 +450,7 @@ static void ensure_pixel_list(DeviceScene *D, const ResolvedOpts &O) {
         for (uint32_t y = y0; y < std::min<uint32_t>(y0 + 32, F.height); ++y)
             for (uint32_t x = x0; x < std::min<uint32_t>(x0 + 32, F.width); ++x) px.push_back(y * F.width + x);
     }
+    D->release(D->pixel_list); D->release(D->pixel_slot); D->pixel_list = nullptr; D->pixel_slot = nullptr;
     D->pixel_list = D->track(dev_upload(px.data(), px.size(), D->stream));
     std::vector<uint32_t> inv((size_t) F.width * F.height, 0u);
     for (size_t k = 0; k < px.size(); ++k) inv[px[k]] = (uint32_t) k;
@@ -579,7 +585,7 @@ void device_render(DeviceScene *D, const lrt_scene_desc &d, const lrt_render_opt
     const uint64_t n_lanes = (uint64_t) D->n_owned_pixels * O.spp;            // this rank's lanes of ONE pass
     float *film = nullptr;
     if (on_device && film_raw) film = film_raw;
-    else { if (D->film_floats < film_floats) { HIP_CHECK(hipMalloc((void **) &D->film, film_floats * 4)); D->track(D->film); D->film_floats = film_floats; } film = D->film; }
+    else { if (D->film_floats < film_floats) { D->release(D->film); D->film = nullptr; HIP_CHECK(hipMalloc((void **) &D->film, film_floats * 4)); D->track(D->film); D->film_floats = film_floats; } film = D->film; }
     HIP_CHECK(hipMemsetAsync(film, 0, film_floats * 4, D->stream));
     const uint32_t *pixel_list = O.tile_count > 1 ? D->pixel_list : nullptr;
     const bool carry = O.n_passes > 1 && d.sampler_type != LRT_SAMPLER_LD;     // the independent sampler's streams run on from pass to pass
@@ -620,7 +626,7 @@ void device_render(DeviceScene *D, const lrt_scene_desc &d, const lrt_render_opt
     stats = total;
     if (image) {
         float *img = image;
-        if (!on_device) { if (D->image_floats < image_floats) { HIP_CHECK(hipMalloc((void **) &D->image, image_floats * 4)); D->track(D->image); D->image_floats = image_floats; } img = D->image; }
+        if (!on_device) { if (D->image_floats < image_floats) { D->release(D->image); D->image = nullptr; HIP_CHECK(hipMalloc((void **) &D->image, image_floats * 4)); D->track(D->image); D->image_floats = image_floats; } img = D->image; }
         k_develop<<<(uint32_t) ((np + 255) / 256), 256, 0, D->stream>>>(F, film, img, (uint32_t) np);
         if (!on_device) HIP_CHECK(hipMemcpyAsync(image, img, image_floats * 4, hipMemcpyDeviceToHost, D->stream));
     }
@@ -635,8 +641,8 @@ void device_develop(DeviceScene *D, const float *film_raw, float *image, int on_
     size_t np = (size_t) F.width * F.height, film_floats = np * F.channels, image_floats = np * (F.has_alpha ? 4 : 3);
     const float *film = film_raw; float *img = image;
     if (!on_device) {
-        if (D->film_floats < film_floats) { HIP_CHECK(hipMalloc((void **) &D->film, film_floats * 4)); D->track(D->film); D->film_floats = film_floats; }
-        if (D->image_floats < image_floats) { HIP_CHECK(hipMalloc((void **) &D->image, image_floats * 4)); D->track(D->image); D->image_floats = image_floats; }
+        if (D->film_floats < film_floats) { D->release(D->film); D->film = nullptr; HIP_CHECK(hipMalloc((void **) &D->film, film_floats * 4)); D->track(D->film); D->film_floats = film_floats; }
+        if (D->image_floats < image_floats) { D->release(D->image); D->image = nullptr; HIP_CHECK(hipMalloc((void **) &D->image, image_floats * 4)); D->track(D->image); D->image_floats = image_floats; }
         HIP_CHECK(hipMemcpyAsync(D->film, film_raw, film_floats * 4, hipMemcpyHostToDevice, D->stream));
         film = D->film; img = D->image;
     }
@@ -699,8 +705,11 @@ namespace lrt {
 // adjoint replay accumulating d(sum(image * grad_image)) / d(sigma_t, albedo, g) into 7 doubles.
 void device_render_backward(DeviceScene *D, const lrt_scene_desc &d, const lrt_render_opts *opts, const float *grad_image, lrt_param_grads *out, lrt_render_stats &stats) {
     HIP_CHECK(hipSetDevice(D->device));
-    ResolvedOpts O = resolve(d, opts);
-    O.integrator = LRT_INTEGRATOR_PRBVOLPATH;
+    lrt_render_opts oprb = opts ? *opts : lrt_render_opts{ -1, -2, -1, -1, 0, 0, 0, 1, 0, 0, 0, 0 };
+    oprb.integrator = LRT_INTEGRATOR_PRBVOLPATH;                               // resolve as the adjoint integrator: RBIntegrator.render_backward has no pass split (common.py prepare())
+    ResolvedOpts O = resolve(d, &oprb);
+    const int grad_medium = opts ? opts->grad_medium : 0;
+    if (grad_medium < -1 || grad_medium >= (int) d.n_media) throw std::runtime_error("lrt_render_backward: grad_medium " + std::to_string(grad_medium) + " is not a medium of the scene");
     hipStream_t st = D->stream;
     const DFilm &F = D->sc.film;
     const size_t np = (size_t) F.width * F.height, T = F.has_alpha ? 4 : 3;
@@ -709,6 +718,7 @@ void device_render_backward(DeviceScene *D, const lrt_scene_desc &d, const lrt_r
     const uint64_t n_lanes = (uint64_t) D->n_owned_pixels * O.spp;
     const uint32_t *pixel_list = O.tile_count > 1 ? D->pixel_list : nullptr;
     DRenderParams rp = make_params(d, O, n_lanes);
+    rp.grad_medium = grad_medium;
     // primal radiance of every lane of a pass is kept (16 B / lane); passes of at most 2^28 lanes bound that buffer to 4.3 GB
     const uint64_t pass = std::min<uint64_t>(std::max<uint64_t>(n_lanes, 1), 1ull << 28);
     PoolGeometry g = pool_geometry(D, pass);
@@ -717,12 +727,12 @@ void device_render_backward(DeviceScene *D, const lrt_scene_desc &d, const lrt_r
     ensure_workspace(D, records); ensure_prb_workspace(D, records, pass);
     const float *g_img = grad_image;
     if (!(opts && opts->output_on_device)) {
-        if (D->grad_floats < np * T) { HIP_CHECK(hipMalloc((void **) &D->grad_image, np * T * 4)); D->track(D->grad_image); D->grad_floats = np * T; }
+        if (D->grad_floats < np * T) { D->release(D->grad_image); D->grad_image = nullptr; HIP_CHECK(hipMalloc((void **) &D->grad_image, np * T * 4)); D->track(D->grad_image); D->grad_floats = np * T; }
         HIP_CHECK(hipMemcpyAsync(D->grad_image, grad_image, np * T * 4, hipMemcpyHostToDevice, st));
         g_img = D->grad_image;
     }
     if (F.rfilter != LRT_RFILTER_BOX) {
-        if (D->wfilm_floats < np) { HIP_CHECK(hipMalloc((void **) &D->wfilm, np * 4)); D->track(D->wfilm); D->wfilm_floats = np; }
+        if (D->wfilm_floats < np) { D->release(D->wfilm); D->wfilm = nullptr; HIP_CHECK(hipMalloc((void **) &D->wfilm, np * 4)); D->track(D->wfilm); D->wfilm_floats = np; }
         HIP_CHECK(hipMemsetAsync(D->wfilm, 0, np * 4, st));
         // sum of reconstruction-filter weights per pixel over every lane of the image (also those of other ranks' tiles)
         uint64_t all = (uint64_t) np * O.spp;

@@ -120,6 +120,7 @@ struct DRenderParams {
     uint32_t base_seed, seed;  // the two terms (the ld sampler keys its per-pixel scramble on them separately)
     uint32_t ld_count, pad1;   // 0: independent sampler; else the ld sampler's sample count (= spp)
     uint32_t tile_rank, tile_count;
+    int32_t grad_medium;       // PRB adjoint: medium whose parameters are differentiated, -1: all media into one set
     uint32_t tiles_x, tiles_y, profile;   // profile: per-region tile timing into DCounters (developer aid, LRT_DEBUG_LAUNCH)
     uint64_t n_lanes;          // lanes this launch renders
     const uint32_t *pixel_slot; // tile-sharded renders: pixel -> index in the rank's pixel list (rank-local lane index), else null

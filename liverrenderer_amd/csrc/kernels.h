@@ -559,7 +559,13 @@ DEV bool path_iteration(const DScene &sc, const DRenderParams &rp, PathState &s,
         result = V3(fma_(throughput.x, em.x, result.x), fma_(throughput.y, em.y, result.y), fma_(throughput.z, em.z, result.z));
     }
     bool active_next = (depth + 1 < max_depth) && si.valid;
-    if (!active_next) { valid_ray = valid_ray || (emitter >= 0 && !rp.hide_emitters); commit(); return false; }
+    if (!active_next) {
+        // path.cpp:227-231: a JIT variant never takes the `dr::none_or<false>` exit; the rest of the trip runs with active_em =
+        // false: six sampler values are drawn (:246, :266-267, :326) and valid_ray |= si.is_valid() && !Null (:305-306)
+        float a0, a1; rng.next2(a0, a1); (void) rng.next(); rng.next2(a0, a1); (void) rng.next();
+        if (si.valid && !(sc.bsdfs[sc.shapes[si.shape].bsdf].flags & F_NULL)) valid_ray = true;
+        commit(); return false;
+    }
     const DShape sd = sc.shapes[si.shape];
     int b = sd.bsdf;
     bool active_em = (sc.bsdfs[b].flags & F_SMOOTH) != 0;
@@ -852,28 +858,33 @@ k_splat_lanes(DScene sc, DRenderParams rp, const float4 *__restrict__ lane_L, co
         const uint32_t k0 = __shfl(key, leader);
         const bool mine = have && key == k0;
         const int gx = __shfl(pix, leader), gy = __shfl(piy, leader);
-        float tr = 0.f, tg = 0.f, tb = 0.f, ta = 0.f, tw = 0.f;         // lane c keeps the totals of footprint cell c
-        for (int ys = 0; ys < count; ++ys) {
+        float tr = 0.f, tg = 0.f, tb = 0.f, ta = 0.f, tw = 0.f;         // lane c keeps the totals of footprint cell (chunk base + c)
+        const int n_cells = count * count;
+        for (int ys = 0, ci = 0; ys < count; ++ys) {
             const float wy = mine ? rfilter_eval(F, rely + (float) ys) : 0.f;
-            for (int xs = 0; xs < count; ++xs) {
+            for (int xs = 0; xs < count; ++xs, ++ci) {
                 const float w = mine ? wy * rfilter_eval(F, relx + (float) xs) : 0.f;
                 float r = L.x * w, g = L.y * w, b = L.z * w, a = alpha * w, ww = w;
                 for (int off = 32; off > 0; off >>= 1) {
                     if (!WEIGHTS_ONLY) { r += __shfl_xor(r, off); g += __shfl_xor(g, off); b += __shfl_xor(b, off); a += __shfl_xor(a, off); }
                     ww += __shfl_xor(ww, off);
                 }
-                if ((int) me == ys * count + xs) { tr = r; tg = g; tb = b; ta = a; tw = ww; }
-            }
-        }
-        if ((int) me < count * count && tw != 0.f) {
-            const int ys = (int) me / count, xs = (int) me - ys * count;
-            const int x = gx - F.crop_offset_x + xs, y = gy - F.crop_offset_y + ys;
-            if (x >= 0 && x < F.width && y >= 0 && y < F.height) {
-                if (WEIGHTS_ONLY) atomicAdd(film + (size_t) y * F.width + x, tw);
-                else {
-                    float *p = film + ((size_t) y * F.width + x) * C;
-                    atomicAdd(p + 0, tr); atomicAdd(p + 1, tg); atomicAdd(p + 2, tb);
-                    if (F.has_alpha) { atomicAdd(p + 3, ta); atomicAdd(p + 4, tw); } else atomicAdd(p + 3, tw);
+                if ((int) me == (ci & 63)) { tr = r; tg = g; tb = b; ta = a; tw = ww; }
+                if ((ci & 63) == 63 || ci == n_cells - 1) {            // a chunk of (up to) 64 cells is complete: lane c flushes cell base + c
+                    const int cell = (ci & ~63) + (int) me;            // (footprints wider than 8 x 8 pixels take several chunks: gaussian stddev > 0.875, tent radius > 3.5)
+                    if (cell <= ci && tw != 0.f) {
+                        const int cy = cell / count, cx = cell - cy * count;
+                        const int x = gx - F.crop_offset_x + cx, y = gy - F.crop_offset_y + cy;
+                        if (x >= 0 && x < F.width && y >= 0 && y < F.height) {
+                            if (WEIGHTS_ONLY) atomicAdd(film + (size_t) y * F.width + x, tw);
+                            else {
+                                float *p = film + ((size_t) y * F.width + x) * C;
+                                atomicAdd(p + 0, tr); atomicAdd(p + 1, tg); atomicAdd(p + 2, tb);
+                                if (F.has_alpha) { atomicAdd(p + 3, ta); atomicAdd(p + 4, tw); } else atomicAdd(p + 3, tw);
+                            }
+                        }
+                    }
+                    tr = tg = tb = ta = tw = 0.f;
                 }
             }
         }

@@ -25,7 +25,7 @@ DEV float hg_dlog_dg(float g, float c) {
 // medium segments the reference backpropagates through (segments that end on a surface with tr_c > 0, :425-427).
 template <typename SMP, typename TR>
 DEV V3 prb_sample_emitter(const DScene &sc, SMP &rng, V3 ref_p, V3 ref_n, bool ref_is_surface, uint32_t ref_shape, V3 ref_geo_n,
-                          int medium, uint32_t channel, DirSample *ds_out, const TR &tr, uint32_t &n_shadow, V3 *seg_sum) {
+                          int medium, uint32_t channel, DirSample *ds_out, const TR &tr, uint32_t &n_shadow, V3 *seg_sum, int grad_medium) {
     float sx, sy; rng.next2(sx, sy);
     DirSample ds; V3 emitter_val = sample_emitter_direction(sc, ref_p, sx, sy, &ds);
     *ds_out = ds;
@@ -54,7 +54,7 @@ DEV V3 prb_sample_emitter(const DScene &sc, SMP &rng, V3 ref_p, V3 ref_n, bool r
             float t = fmin_(remaining_dist, si.t);
             seg_t = fmin_(t, si.t) - 0.f;
             tr_multiplier = V3(m_exp(-seg_t * M.sigma_t[0]), m_exp(-seg_t * M.sigma_t[1]), m_exp(-seg_t * M.sigma_t[2]));
-            scale_t = -seg_t * M.scale;
+            scale_t = (grad_medium < 0 || medium == grad_medium) ? -seg_t * M.scale : 0.f;   // only the differentiated medium's segments
             escaped_medium = true; active_medium = false;
         }
         active_surface = (active_surface || escaped_medium) && si.valid && !active_medium;
@@ -127,7 +127,8 @@ DEV bool prb_iteration(const DScene &sc, const DRenderParams &rp, PathState &s, 
     act_medium_scatter = act_medium_scatter && active;
     if (act_medium_scatter) weight = weight * mei.sigma_s;
     throughput = throughput * weight;
-    if (ADJOINT && in_medium_segment) {                                 // prbvolpath.py:199-204
+    const int gm = rp.grad_medium;
+    if (ADJOINT && in_medium_segment && (gm < 0 || medium == gm)) {     // prbvolpath.py:199-204
         const DMedium M = sc.media[medium];
         auto term = [&](float w, float l, float dl, float st, float al, float &gs, float &ga) {
             float Lo = l / fmax_(1e-8f, w);
@@ -176,7 +177,7 @@ DEV bool prb_iteration(const DScene &sc, const DRenderParams &rp, PathState &s, 
     if (active_e_surface || active_e_medium) {
         DirSample ds; V3 seg_sum;
         V3 rp_ = active_e_medium ? mei.p : si.p, rn = active_e_medium ? V3(0.f) : si.n;
-        V3 emitted = prb_sample_emitter(sc, rng, rp_, rn, active_e_surface, active_e_surface ? si.shape : 0u, si.n, medium, channel, &ds, tr, n_shadow, &seg_sum);
+        V3 emitted = prb_sample_emitter(sc, rng, rp_, rn, active_e_surface, active_e_surface ? si.shape : 0u, si.n, medium, channel, &ds, tr, n_shadow, &seg_sum, gm);
         V3 nee_weight; float nee_pdf;
         if (active_e_surface) { V3 wo = si.sh.to_local(ds.d); nee_weight = bsdf_eval(sc, b, si, wo); nee_pdf = bsdf_pdf(sc, b, si, wo); }
         else { float pv = phase_eval(sc.media[medium], mei.wi, ds.d); nee_weight = V3(pv); nee_pdf = pv; }
@@ -184,7 +185,7 @@ DEV bool prb_iteration(const DScene &sc, const DRenderParams &rp, PathState &s, 
         L = ADJOINT ? L - contrib : L + contrib;
         if (ADJOINT) {
             G.sigma_t[0] += delta_L.x * contrib.x * seg_sum.x; G.sigma_t[1] += delta_L.y * contrib.y * seg_sum.y; G.sigma_t[2] += delta_L.z * contrib.z * seg_sum.z;
-            if (active_e_medium && sc.media[medium].phase == LRT_PHASE_HG)
+            if (active_e_medium && sc.media[medium].phase == LRT_PHASE_HG && (gm < 0 || medium == gm))
                 G.g += (delta_L.x * contrib.x + delta_L.y * contrib.y + delta_L.z * contrib.z) * hg_dlog_dg(sc.media[medium].g, dot(ds.d, mei.wi));
         }
     }
@@ -198,7 +199,7 @@ DEV bool prb_iteration(const DScene &sc, const DRenderParams &rp, PathState &s, 
         V3 wo; float phase_pdf; phase_sample(M, mei.wi, s2x, s2y, &wo, &phase_pdf);
         act_medium_scatter = phase_pdf > 0.f;
         if (act_medium_scatter) {
-            if (ADJOINT && M.phase == LRT_PHASE_HG) {
+            if (ADJOINT && M.phase == LRT_PHASE_HG && (gm < 0 || medium == gm)) {
                 float pe = phase_eval(M, mei.wi, wo), dlg = hg_dlog_dg(M.g, dot(wo, mei.wi));
                 G.g += delta_L.x * (pe * (L.x / fmax_(1e-8f, pe))) * dlg;
                 G.g += delta_L.y * (pe * (L.y / fmax_(1e-8f, pe))) * dlg;

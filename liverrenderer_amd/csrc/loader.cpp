@@ -322,7 +322,10 @@ struct Loader {
     int make_bsdf(const ObjP &o) {
         auto it = bsdf_ix.find(o.get()); if (it != bsdf_ix.end()) return it->second;
         lrt_bsdf_desc B{}; B.reflectance = B.nested = B.texture = -1; B.eta = 1.f; B.scale = 1.f;
-        if (o->type == "diffuse") { B.type = LRT_BSDF_DIFFUSE; B.reflectance = texture_or_rgb(*o, "reflectance", .5f); }
+        if (o->type == "diffuse") {
+            B.type = LRT_BSDF_DIFFUSE; B.reflectance = texture_or_rgb(*o, "reflectance", .5f);
+            if (S.textures[B.reflectance].type == LRT_TEX_BITMAP) fail("unsupported: a bitmap texture as diffuse reflectance (bitmaps are supported as bump-map heights only)");
+        }
         else if (o->type == "dielectric") {
             B.type = LRT_BSDF_DIELECTRIC;
             float ii = lookup_ior(*o, "int_ior", "bk7"), ei = lookup_ior(*o, "ext_ior", "air");

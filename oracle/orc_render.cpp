@@ -514,6 +514,7 @@ static float phase_eval(const lrt_medium_desc &M, V3 wi, V3 wo) {
 /* ------------------------------------------------------------ integrators */
 struct Ctx {
     const Scene &S; Sampler smp; int max_depth, rr_depth; bool hide_emitters;
+    int grad_medium = 0;            /* PRB adjoint: medium whose parameters are differentiated, -1: all media into one set */
     bool bio_jit = true;            /* bio transport: JIT-variant reading (orc_bio.h); false: scalar_rgb reading */
     uint64_t n_iter = 0, n_shadow = 0, n_shadow_needed = 0;
     Ctx(const Scene &s) : S(s), bio_jit(!s.bio_scalar) {}
@@ -795,7 +796,15 @@ static void path_sample(Ctx &C, Ray ray, V3 *out, bool *out_valid) {
             result = V3(fmaf(throughput.x, em.x, result.x), fmaf(throughput.y, em.y, result.y), fmaf(throughput.z, em.z, result.z));
         }
         bool active_next = (depth + 1 < max_depth) && si.valid;
-        if (!active_next) { valid_ray = valid_ray || (emitter >= 0 && !C.hide_emitters); break; }
+        if (!active_next) {
+            /* path.cpp:227-231: `if (dr::none_or<false>(active_next))` is never taken in a JIT variant (its body, with the
+               `valid_ray |= emitter && !hide_emitters` update, is scalar-only): the rest of the trip runs for the lane with
+               active_em = false.  What survives: the six sampler values of :246, :266-267, :326 are drawn, and
+               `valid_ray |= active && si.is_valid() && !Null` (:305-306; the sampled type is Null only for a null BSDF). */
+            float a0, a1; C.next2(&a0, &a1); (void) C.next(); C.next2(&a0, &a1); (void) C.next();
+            if (si.valid && !(bsdf_flags(S, S.shapes[si.shape].bsdf) & F_NULL)) valid_ray = true;
+            break;
+        }
         const lrt_shape_desc &sd = S.shapes[si.shape];
         int b = sd.bsdf;
         bool active_em = (bsdf_flags(S, b) & F_SMOOTH) != 0;
@@ -860,6 +869,7 @@ static inline float hg_dlog_dg(float g, float c) {
    through the per-segment transmittance (homogeneous media: analytic transmittance, :403-407). */
 static V3 prb_sample_emitter(Ctx &C, V3 ref_p, V3 ref_n, const SI *ref_si, int medium, uint32_t channel, DirSample *ds_out,
                              bool adjoint, V3 delta_L, V3 adj_emitted, Grads *G) {
+    const int gm = C.grad_medium;
     const Scene &S = C.S;
     float sx, sy; C.next2(&sx, &sy);
     DirSample ds; V3 emitter_val = sample_emitter_direction(S, ref_p, sx, sy, &ds);
@@ -894,7 +904,7 @@ static V3 prb_sample_emitter(Ctx &C, V3 ref_p, V3 ref_n, const SI *ref_si, int m
         }
         active_surface = (active_surface || escaped_medium) && si.valid && !active_medium;
         if (active_surface) tr_multiplier *= bsdf_null_transmission(S, S.shapes[si.shape].bsdf);
-        if (adjoint && escaped_medium && active_surface) {           /* :425-427, active_adj = (surface | medium) & tr > 0 */
+        if (adjoint && escaped_medium && active_surface && (gm < 0 || medium == gm)) {   /* :425-427, active_adj = (surface | medium) & tr > 0 */
             const lrt_medium_desc &M = S.media[medium];
             float c[3] = { tr_multiplier.x, tr_multiplier.y, tr_multiplier.z }, dl[3] = { delta_L.x, delta_L.y, delta_L.z }, ae[3] = { adj_emitted.x, adj_emitted.y, adj_emitted.z };
             for (int k = 0; k < 3; ++k) if (c[k] > 0.f) G->sigma_t[k] += (double) (dl[k] * ae[k] * (-seg_t) * M.scale);
@@ -956,7 +966,8 @@ static void prb_sample(Ctx &C, Ray ray, bool adjoint, V3 delta_L, V3 L_in, V3 *L
         act_medium_scatter = act_medium_scatter && active;
         if (act_medium_scatter) weight *= mei.sigma_s;
         throughput *= weight;
-        if (adjoint && in_medium_segment) {                                         /* :199-204 */
+        const int gm = C.grad_medium;
+        if (adjoint && in_medium_segment && (gm < 0 || medium == gm)) {             /* :199-204 */
             const lrt_medium_desc &M = S.media[medium];
             float w[3] = { weight.x, weight.y, weight.z }, l[3] = { L.x, L.y, L.z }, dl[3] = { delta_L.x, delta_L.y, delta_L.z };
             for (int k = 0; k < 3; ++k) {
@@ -1018,7 +1029,7 @@ static void prb_sample(Ctx &C, Ray ray, bool adjoint, V3 delta_L, V3 L_in, V3 *L
                 DirSample ds2;
                 prb_sample_emitter(C, rp, rn, active_e_surface ? &si : nullptr, medium, channel, &ds2, true, delta_L, contrib, G);
                 C.smp = saved; C.n_shadow = ns; C.n_shadow_needed = nn;
-                if (active_e_medium && S.media[medium].phase == LRT_PHASE_HG) {    /* backward(dL * contrib) through phase_val */
+                if (active_e_medium && S.media[medium].phase == LRT_PHASE_HG && (gm < 0 || medium == gm)) {    /* backward(dL * contrib) through phase_val */
                     float dlg = hg_dlog_dg(S.media[medium].g, dot(ds.d, mei.wi));
                     G->g += (double) ((delta_L.x * contrib.x + delta_L.y * contrib.y + delta_L.z * contrib.z) * dlg);
                 }
@@ -1034,7 +1045,7 @@ static void prb_sample(Ctx &C, Ray ray, bool adjoint, V3 delta_L, V3 L_in, V3 *L
             V3 wo; float phase_pdf; phase_sample(M, mei.wi, s2x, s2y, &wo, &phase_pdf);
             act_medium_scatter = phase_pdf > 0.f;
             if (act_medium_scatter) {
-                if (adjoint && M.phase == LRT_PHASE_HG) {
+                if (adjoint && M.phase == LRT_PHASE_HG && (gm < 0 || medium == gm)) {
                     float pe = phase_eval(M, mei.wi, wo);
                     float dlg = hg_dlog_dg(M.g, dot(wo, mei.wi));
                     float l[3] = { L.x, L.y, L.z }, dl[3] = { delta_L.x, delta_L.y, delta_L.z };
@@ -1384,7 +1395,10 @@ extern "C" int orc_render_backward(orc_scene *s, const lrt_render_opts *opts, in
     if (N > 0xffffffffull) { g_err = "orc_render_backward: more than 2^32 lanes"; return 1; }
     const bool box = F.rfilter == LRT_RFILTER_BOX;
     int nt = hw_threads(n_threads);
+    const int grad_medium = opts ? opts->grad_medium : 0;
+    if (grad_medium < -1 || grad_medium >= (int) S.d.n_media) { g_err = "orc_render_backward: grad_medium is not a medium of the scene"; return 1; }
     auto lane_setup = [&](uint64_t lane, Ctx &C, float *spx, float *spy, Ray *ray) {
+        C.grad_medium = grad_medium;
         C.max_depth = O.max_depth; C.rr_depth = O.rr_depth; C.hide_emitters = O.hide_emitters;
         C.smp = lane_sampler(S.d.sampler_type, S.d.sampler_seed, O.seed, (uint32_t) lane, O.spp);
         uint32_t idx = (uint32_t) (lane / O.spp), py = idx / (uint32_t) W, px = idx - py * (uint32_t) W;

@@ -1,10 +1,10 @@
 """Summarise a rocprofv3 output directory produced by scripts/profile_bench.sh.
 Prints the kernel-trace stats table, the PMC counters of this library's kernels (per dispatch), derived figures for the
 render kernel, and writes <out>/traffic.json (HBM bytes per launch of the render kernel; both counters are in KiB).
-FETCH_SIZE is scaled by FETCH_FACTOR, calibrated on this kernel's own access pattern against a known byte count as
-MI355X_MICROARCH.md "HBM" asks for patterns it did not calibrate (profiles/r01_fetch_size_calibration.txt: the guide's x2
-for one wide streaming read over-corrects here by 1.8x); WRITE_SIZE is read as is."""
-FETCH_FACTOR = 1.118
+FETCH_SIZE is doubled (MI355X_MICROARCH.md "HBM": on gfx950 it reports 1/2 of the bytes of wide coalesced stream loads), which
+profiles/r02_stream_calibration.txt reproduces on this kernel's own record streams with a known byte count (x2.000 / x1.980);
+WRITE_SIZE is read as is (x1.000 in the same calibration)."""
+FETCH_FACTOR = 2.0
 import csv, glob, json, os, sys, collections
 out = sys.argv[1]
 def find(pattern):
@@ -36,7 +36,7 @@ for k in agg:
         print(f"   wave cycles waiting {a['SQ_WAIT_ANY'] / a['SQ_WAVE_CYCLES']:.1%}")
     if "FETCH_SIZE" in a and "WRITE_SIZE" in a:
         rd, wr = a["FETCH_SIZE"] * 1024 * FETCH_FACTOR, a["WRITE_SIZE"] * 1024
-        print(f"   HBM traffic per launch: read {rd / 1e9:.2f} GB (FETCH_SIZE x {FETCH_FACTOR}, calibrated), write {wr / 1e9:.2f} GB, total {(rd + wr) / 1e9:.2f} GB")
+        print(f"   HBM traffic per launch: read {rd / 1e9:.2f} GB (FETCH_SIZE x {FETCH_FACTOR}), write {wr / 1e9:.2f} GB, total {(rd + wr) / 1e9:.2f} GB")
         workload = None
         try:
             line = [l for l in open(os.path.join(out, "bench_trace.log")) if l.startswith("{")][-1]
@@ -46,5 +46,5 @@ for k in agg:
         json.dump({"kernel": k, "workload": workload, "read_bytes_per_launch": rd, "write_bytes_per_launch": wr,
                    "traffic_bytes_per_launch": rd + wr, "bench_args": sys.argv[2:],
                    "fetch_factor": FETCH_FACTOR,
-                   "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), KiB; FETCH_SIZE x fetch_factor, calibrated on this kernel (profiles/r01_fetch_size_calibration.txt)"},
+                   "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), KiB; FETCH_SIZE x fetch_factor (guide value, reproduced on the record streams: profiles/r02_stream_calibration.txt)"},
                   open(os.path.join(out, "traffic.json"), "w"), indent=1)

@@ -143,7 +143,7 @@ class OrcScene:
     def render_backward(self, grad_image, threads=0, **kw):
         g = np.ascontiguousarray(grad_image, np.float32)
         o = _lib.make_opts(kw.get("integrator"), kw.get("max_depth"), kw.get("rr_depth"), kw.get("hide_emitters"),
-                           kw.get("spp", 0), kw.get("seed", 0))
+                           kw.get("spp", 0), kw.get("seed", 0), grad_medium=kw.get("medium", 0))
         out = _lib.ParamGrads()
         if self._L.orc_render_backward(self._h, C.byref(o), threads, g.ctypes.data, C.byref(out)) != 0:
             raise RuntimeError("orc_render_backward failed")
