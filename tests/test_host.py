@@ -264,3 +264,58 @@ def test_scene_from_buffers_validation(mi):
         mi.scene_from_buffers(v, np.array([[0, 1, 7]], np.uint32))
     sc = mi.scene_from_buffers(v, np.array([[0, 1, 2]], np.uint32), constant_radiance=(1, 2, 3))
     assert sc.desc.n_emitters == 1 and list(sc.desc.emitters[0].radiance) == [1, 2, 3]
+
+
+def test_round2_rejections(mi):
+    """a bitmap as diffuse reflectance renders black silently -> rejected; `g` of an isotropic phase function."""
+    assets = os.path.join(ROOT, "scenes", "assets")
+    xml = f'''<scene version="3.0.0"><sensor type="perspective"/>
+      <shape type="cube"><bsdf type="diffuse"><texture name="reflectance" type="bitmap"><string name="filename" value="{assets}/tissue_n.png"/></texture></bsdf></shape></scene>'''
+    with pytest.raises(RuntimeError, match="bitmap texture as diffuse reflectance"):
+        mi.load_string(xml)
+    sc = mi.load_file(LIVER_XML, integrator="volpath")
+    with pytest.raises(RuntimeError, match="isotropic"):
+        sc.param_set("LiverMedium.phase_function.g", 0.0)
+    sc.param_set("LiverMedium.phase_function.g", 0.5)              # the documented extension: a non-zero g makes it hg
+    sc.param_set("LiverMedium.phase_function.g", 0.0)              # ... and g = 0 is then an ordinary value
+    assert sc.param_get("LiverMedium.phase_function.g", 1)[0] == 0.0
+    p = mi.traverse(sc); p["LiverMedium.phase_function.g"] = 0.0; p.update()
+
+
+def test_scene_from_desc_validation(mi):
+    """lrt_scene_from_desc checks every index, range and pointer of a caller-built description (ADVICE r1)."""
+    import copy
+    from liverrenderer_amd import _lib
+    base = mi.load_dict(mi.cornell_box())
+    L = _lib.lib()
+
+    def attempt(mutate):
+        d = _lib.SceneDesc.from_buffer_copy(base.desc)              # shallow copy: arrays still point into `base`
+        arrays = {}
+        def clone(name, typ, n):
+            arr = (typ * n)(*[getattr(d, name)[i] for i in range(n)]); arrays[name] = arr
+            setattr(d, name, C.cast(arr, C.POINTER(typ))); return arr
+        sh, bs, em, tx = clone("shapes", _lib.ShapeDesc, d.n_shapes), clone("bsdfs", _lib.BsdfDesc, d.n_bsdfs), clone("emitters", _lib.EmitterDesc, d.n_emitters), clone("textures", _lib.TextureDesc, d.n_textures)
+        mutate(d, sh, bs, em, tx)
+        h = C.c_void_p()
+        st = L.lrt_scene_from_desc(C.byref(d), C.byref(h))
+        if st == 0: L.lrt_scene_free(h)
+        return st, L.lrt_last_error().decode()
+
+    assert attempt(lambda d, sh, bs, em, tx: None)[0] == 0
+    cases = {
+        "emitter shape": lambda d, sh, bs, em, tx: setattr(em[0], "shape", 99),
+        "emitter on a mesh": lambda d, sh, bs, em, tx: setattr(em[0], "shape", 6),
+        "bsdf texture": lambda d, sh, bs, em, tx: setattr(bs[0], "reflectance", 17),
+        "sensor medium": lambda d, sh, bs, em, tx: setattr(d.sensor, "medium", 0),
+        "face range": lambda d, sh, bs, em, tx: setattr(sh[7], "n_faces", 1000),
+        "crop window": lambda d, sh, bs, em, tx: setattr(d.film, "crop_width", 9999),
+        "shape medium": lambda d, sh, bs, em, tx: setattr(sh[1], "interior_medium", 3),
+        "integrator": lambda d, sh, bs, em, tx: setattr(d.integrator, "type", 9),
+        "texture type": lambda d, sh, bs, em, tx: setattr(tx[0], "type", 5),
+        "bitmap without data": lambda d, sh, bs, em, tx: (setattr(tx[0], "type", 2), setattr(tx[0], "width", 4), setattr(tx[0], "height", 4), setattr(tx[0], "channels", 1)),
+        "fov": lambda d, sh, bs, em, tx: setattr(d.sensor, "fov_x", 0.0),
+    }
+    for name, fn in cases.items():
+        st, msg = attempt(fn)
+        assert st != 0 and msg, name
