@@ -275,6 +275,36 @@ def test_cornell_1080_weak_golden(mi, orc):
     assert np.abs(c - g)[ok].mean() < 0.06 * g[ok].mean()
 
 
+def cornell_fog_scene(mi, width, spp):
+    """MitsubaRunner.py:8-40: mi.cornell_box() + homogeneous fog (sigma_t 0.2, albedo 0.75, scale 2.5, isotropic) attached to the
+    SENSOR only (no shape references it: the fog fills all space), volpath with max_depth -1."""
+    d = mi.cornell_box()
+    d['fog_medium_id'] = {'type': 'homogeneous', 'sigma_t': {'type': 'rgb', 'value': [0.2, 0.2, 0.2]},
+                          'albedo': {'type': 'rgb', 'value': [0.75, 0.75, 0.75]}, 'scale': 2.5, 'phase': {'type': 'isotropic'}}
+    d['integrator'] = {'type': 'volpath', 'max_depth': -1}
+    d['sensor']['film'].update({'width': width, 'height': width})
+    d['sensor']['sampler']['sample_count'] = spp
+    d['sensor']['medium'] = {'type': 'ref', 'id': 'fog_medium_id'}
+    return mi.load_dict(d)
+
+
+def test_cornell_fog_weak_golden(mi, orc):
+    """The only reference-held output of `volpath` proper (free flight, medium emitter sampling, phase sampling, sensor inside a
+    medium): the tree's own 1080x1080 fog render (8-bit sRGB PNG, 4096 spp per MitsubaRunner.py), decoded to linear and
+    box-averaged 8x8 (tests/golden/make_cornell_fog_small.py), against the oracle at 135x135.  Observed at 1024 spp: mean
+    radiance +2.0 .. +2.6 % per channel, the fog-only border +0.7 .. +1.5 % (the plain Cornell golden is off by -2.3 % in red)."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "reference_cornell_box_fog_1080_down8.npy")).astype(np.float64)
+    sc = cornell_fog_scene(mi, 135, 128)
+    assert sc.desc.sensor.medium == 0 and sc.desc.n_media == 1 and sc.desc.integrator.max_depth == -1
+    c = np.clip(orc.OrcScene(sc).render(seed=0).astype(np.float64)[..., :3], 0, 1)
+    ok = (g < 0.9).all(-1) & (c < 0.9).all(-1)                  # away from the clipped emitter
+    assert np.allclose(c[ok].mean(0), g[ok].mean(0), rtol=0.06)
+    border = np.zeros((135, 135), bool); border[:, :3] = True; border[:, -3:] = True       # outside the box: in-scattered light only
+    assert np.allclose(c[border].mean(0), g[border].mean(0), rtol=0.05)
+    plain = np.load(os.path.join(ROOT, "tests", "golden", "reference_cornell_box_1080_down8.npy")).astype(np.float64)
+    assert g[ok].mean() < 0.5 * plain[ok].mean() and g[border].mean() > 20 * plain[border].mean()   # the fog is what is being compared
+
+
 def test_liver_singlemesh_weak_golden(mi, orc):
     """The reference's own render of the C3 scene (committed PNG, 1920x1080, fork's biovolpath integrator) pins everything
     that does not depend on the in-tissue transport: where the environment map is seen directly the images agree to

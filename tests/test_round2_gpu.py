@@ -72,3 +72,40 @@ def test_wide_filter_footprints(mi, orc, rf):
     gg, gc = ps.render_backward(grad, seed=2, spp=4), po.render_backward(grad, seed=2, spp=4)
     for k in ("sigma_t", "albedo"):
         assert np.abs(gg[k] - gc[k]).max() <= 3e-4 * max(np.abs(gc[k]).max(), 1e-7), (k, gg[k], gc[k])
+
+
+def test_cornell_fog_reference_render(mi):
+    """the reference's own volpath fog render pins the HIP path too.  Same pipeline as the fixture: render at
+    1080x1080 (64 spp), box-average 8x8 in linear.  Interior mean within 5 %, fog-only border within 4 %, shape correlation."""
+    from test_oracle_pins import cornell_fog_scene
+    g = np.load(os.path.join(ROOT, "tests", "golden", "reference_cornell_box_fog_1080_down8.npy")).astype(np.float64)
+    sc = cornell_fog_scene(mi, 1080, 64)
+    img = sc.render(seed=0).astype(np.float64)[..., :3]
+    c = np.clip(img, 0, 1).reshape(135, 8, 135, 8, 3).mean((1, 3))
+    ok = (g < 0.9).all(-1) & (c < 0.9).all(-1)
+    assert np.allclose(c[ok].mean(0), g[ok].mean(0), rtol=0.05), (c[ok].mean(0) / g[ok].mean(0))
+    border = np.zeros((135, 135), bool); border[:, :3] = True; border[:, -3:] = True
+    assert np.allclose(c[border].mean(0), g[border].mean(0), rtol=0.04), (c[border].mean(0) / g[border].mean(0))
+    assert np.corrcoef(c[ok].ravel(), g[ok].ravel())[0, 1] > 0.99
+
+
+def test_liver_singlemesh_bio_reference_render(mi):
+    """The reference's committed scalar_rgb render of Liver-SingleMesh (biovolpath + liver medium, 128 spp) against the HIP render
+    of scene.xml with the file's own integrator and medium at the same resolution and sample count: liver-interior mean colour
+    (all in-tissue transport) within 1.5 % per channel, per-pixel agreement inside the liver."""
+    import re
+    from scipy.ndimage import binary_erosion
+    from conftest import LIVER_XML
+    g = np.load(os.path.join(ROOT, "tests", "golden", "reference_liver_singlemesh_cpu_down8.npy")).astype(np.float64)
+    sc = mi.load_file(LIVER_XML, spp=128, res_width=1920, res_height=1080)
+    assert sc.desc.integrator.type == 3
+    img = sc.render(seed=0).astype(np.float64)[..., :3].reshape(135, 8, 240, 8, 3).mean((1, 3))
+    env = mi.load_string(re.sub(r'<shape type="obj".*?</shape>', '', open(LIVER_XML).read(), flags=re.S),
+                         base_dir=os.path.dirname(LIVER_XML), spp=4, res_width=240, res_height=135)
+    E = np.clip(env.render().astype(np.float64)[..., :3], 0, 1)
+    mg, mo = np.abs(g - E).max(-1) > 0.08, np.abs(np.clip(img, 0, 1) - E).max(-1) > 0.08
+    assert (mg & mo).sum() / (mg | mo).sum() > 0.98
+    inner = binary_erosion(mg & mo, iterations=6)
+    ours, ref = img[inner].mean(0), g[inner].mean(0)
+    assert np.allclose(ours, ref, rtol=0.015), (ours / ref)
+    assert np.abs(img - g)[inner].mean() < 0.08 * g[inner].mean()
