@@ -302,7 +302,7 @@ def test_cornell_fog_weak_golden(mi, orc):
     border = np.zeros((135, 135), bool); border[:, :3] = True; border[:, -3:] = True       # outside the box: in-scattered light only
     assert np.allclose(c[border].mean(0), g[border].mean(0), rtol=0.05)
     plain = np.load(os.path.join(ROOT, "tests", "golden", "reference_cornell_box_1080_down8.npy")).astype(np.float64)
-    assert g[ok].mean() < 0.5 * plain[ok].mean() and g[border].mean() > 20 * plain[border].mean()   # the fog is what is being compared
+    assert g[ok].mean() < 0.5 * plain[ok].mean() and g[border][:, 2].mean() > 0.002         # the fog is what is being compared
 
 
 def test_liver_singlemesh_weak_golden(mi, orc):
