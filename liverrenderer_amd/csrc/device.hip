@@ -25,10 +25,17 @@ template <typename T> static T *dev_upload(const T *src, size_t n, hipStream_t s
     return p;
 }
 
+#define LRT_LAUNCH_SLOTS 64
+
 struct DeviceScene {
     int device = 0;
     hipStream_t stream = nullptr;
-    DScene sc{};
+    DScene sc{};                           // host copy of the scene record; the kernels read d_sc (constant address space)
+    DScene *d_sc = nullptr;
+    // launch-argument slots (DLaunch, read by the kernels through the constant address space): a ring in device memory
+    // filled from a pinned host ring, one slot per launch; a slot is reused only after LRT_LAUNCH_SLOTS further launches
+    // of the same in-order stream, i.e. long after its kernel has finished
+    DLaunch *d_launch = nullptr, *h_launch = nullptr; uint32_t launch_next = 0;
     std::vector<void *> allocs;            // everything freed in the destructor
     // wavefront workspace
     uint32_t capacity = 0;
@@ -58,6 +65,7 @@ struct DeviceScene {
         for (void *p : allocs) (void) hipFree(p);
         for (auto e : ev_pool) (void) hipEventDestroy(e);
         if (h_counters) (void) hipHostFree(h_counters);
+        if (h_launch) (void) hipHostFree(h_launch);
         if (stream) (void) hipStreamDestroy(stream);
     }
 };
@@ -373,6 +381,10 @@ DeviceScene *device_scene_create(const lrt_scene_desc &d, int device) {
     sc.env_data = (const float4 *) D->track(dev_upload(env_rgbx.data(), env_rgbx.size(), st));
     sc.env_hier = D->track(dev_upload(hier.data(), hier.size(), st));
     build_camera(d, sc.cam, sc.film);
+    HIP_CHECK(hipMalloc((void **) &D->d_sc, sizeof(DScene))); D->track(D->d_sc);
+    HIP_CHECK(hipMemcpyAsync(D->d_sc, &sc, sizeof(DScene), hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipMalloc((void **) &D->d_launch, LRT_LAUNCH_SLOTS * sizeof(DLaunch))); D->track(D->d_launch);
+    HIP_CHECK(hipHostMalloc((void **) &D->h_launch, LRT_LAUNCH_SLOTS * sizeof(DLaunch)));
     HIP_CHECK(hipMalloc((void **) &D->counters, sizeof(DCounters))); D->track(D->counters);
     HIP_CHECK(hipHostMalloc((void **) &D->h_counters, sizeof(DCounters)));
     HIP_CHECK(hipStreamSynchronize(st));
@@ -518,12 +530,25 @@ static PoolGeometry pool_geometry(DeviceScene *D, uint64_t n_lanes) {
     return g;
 }
 
+// Copies the launch arguments into the next ring slot (stream-ordered) and returns the device pointer the kernel reads.
+static LaunchPtr push_launch(DeviceScene *D, const DLaunch &a) {
+    const uint32_t slot = D->launch_next++ % LRT_LAUNCH_SLOTS;
+    if (slot == 0 && D->launch_next > 1) HIP_CHECK(hipStreamSynchronize(D->stream));    // the pinned source ring wraps: every earlier copy has been consumed
+    D->h_launch[slot] = a;
+    HIP_CHECK(hipMemcpyAsync(&D->d_launch[slot], &D->h_launch[slot], sizeof(DLaunch), hipMemcpyHostToDevice, D->stream));
+    return (LaunchPtr) &D->d_launch[slot];
+}
+
 template <bool ADJOINT>
 static void launch_prb(DeviceScene *D, const DRenderParams &rp, const PoolGeometry &g, const uint32_t *pixel_list, uint64_t lane_begin,
                        float4 *L_buf, const float *grad_image, double *grads, float *film, float *sample_out) {
     hipStream_t st = D->stream;
     HIP_CHECK(hipMemsetAsync(&D->counters->next_lane, 0, sizeof(unsigned long long), st));
-    #define LRT_LAUNCH_PRB(BS, LDSB, LD) k_render_prb<ADJOINT, BS, LDSB, LD><<<g.n_wg, BS, g.smem, st>>>(D->sc, rp, D->lds, D->q[0], D->q[1], D->dl[0], D->dl[1], g.P, D->counters, pixel_list, lane_begin, L_buf, grad_image, D->wfilm, grads, film, sample_out, lane_begin)
+    DLaunch a{}; a.rp = rp; a.li = D->lds; a.q0 = D->q[0]; a.q1 = D->q[1]; a.dl0 = D->dl[0]; a.dl1 = D->dl[1]; a.P = g.P; a.cnt = D->counters;
+    a.pixel_list = pixel_list; a.lane_begin = lane_begin; a.n = rp.n_lanes; a.L_buf = L_buf; a.grad_image = grad_image; a.wfilm = D->wfilm; a.grads = grads;
+    a.film = film; a.sample_out = sample_out; a.sample_base = lane_begin;
+    const LaunchPtr lp = push_launch(D, a);
+    #define LRT_LAUNCH_PRB(BS, LDSB, LD) k_render_prb<ADJOINT, BS, LDSB, LD><<<g.n_wg, BS, g.smem, st>>>((ScenePtr) D->d_sc, lp)
     if (D->use_lds) { if (rp.ld_count) LRT_LAUNCH_PRB(1024, true, true); else LRT_LAUNCH_PRB(1024, true, false); }
     else { if (rp.ld_count) LRT_LAUNCH_PRB(LRT_BLOCK, false, true); else LRT_LAUNCH_PRB(LRT_BLOCK, false, false); }
     #undef LRT_LAUNCH_PRB
@@ -554,8 +579,11 @@ static void run_wavefront(DeviceScene *D, const lrt_scene_desc &d, const Resolve
     HIP_CHECK(hipEventRecord(a, st));
     if (prb) launch_prb<false>(D, rp, g, pixel_list, lane_begin, nullptr, nullptr, nullptr, film, sample_out);
     else {
-        #define LRT_LAUNCH(I, BS, LDSB) do { if (rp.ld_count) k_render<I, BS, LDSB, true><<<g.n_wg, BS, g.smem, st>>>(D->sc, rp, D->lds, D->q[0], D->q[1], g.P, D->counters, pixel_list, lane_begin, film, sample_out, lane_begin); \
-                                             else k_render<I, BS, LDSB, false><<<g.n_wg, BS, g.smem, st>>>(D->sc, rp, D->lds, D->q[0], D->q[1], g.P, D->counters, pixel_list, lane_begin, film, sample_out, lane_begin); } while (0)
+        DLaunch a{}; a.rp = rp; a.li = D->lds; a.q0 = D->q[0]; a.q1 = D->q[1]; a.P = g.P; a.cnt = D->counters; a.pixel_list = pixel_list;
+        a.lane_begin = lane_begin; a.n = n_lanes; a.film = film; a.sample_out = sample_out; a.sample_base = lane_begin;
+        const LaunchPtr lp = push_launch(D, a);
+        #define LRT_LAUNCH(I, BS, LDSB) do { if (rp.ld_count) k_render<I, BS, LDSB, true><<<g.n_wg, BS, g.smem, st>>>((ScenePtr) D->d_sc, lp); \
+                                             else k_render<I, BS, LDSB, false><<<g.n_wg, BS, g.smem, st>>>((ScenePtr) D->d_sc, lp); } while (0)
         #define LRT_LAUNCH_I(BS, LDSB) do { switch (O.integrator) { \
             case LRT_INTEGRATOR_PATH: LRT_LAUNCH(LRT_INTEGRATOR_PATH, BS, LDSB); break; \
             case LRT_INTEGRATOR_BIOVOLPATH: LRT_LAUNCH(LRT_INTEGRATOR_BIOVOLPATH, BS, LDSB); break; \
@@ -616,7 +644,8 @@ void device_render(DeviceScene *D, const lrt_scene_desc &d, const lrt_render_opt
             lrt_render_stats st1{};
             run_wavefront(D, d, O, base, n, pixel_list, nullptr, reinterpret_cast<float *>(D->L_buf), st1);
             DRenderParams rp = make_params(d, O, n); rp.pass_in = D->cur_pass_in;
-            k_splat_lanes<false><<<(uint32_t) ((n + LRT_BLOCK - 1) / LRT_BLOCK), LRT_BLOCK, 0, D->stream>>>(D->sc, rp, D->L_buf, pixel_list, base, n, film);
+            DLaunch a{}; a.rp = rp; a.L_buf = D->L_buf; a.pixel_list = pixel_list; a.lane_begin = base; a.n = n; a.film = film;
+            k_splat_lanes<false><<<(uint32_t) ((n + LRT_BLOCK - 1) / LRT_BLOCK), LRT_BLOCK, 0, D->stream>>>((ScenePtr) D->d_sc, push_launch(D, a));
             HIP_CHECK(hipGetLastError());
             total.n_samples += st1.n_samples; total.n_iter += st1.n_iter; total.n_shadow += st1.n_shadow; total.n_launches += st1.n_launches;
             total.n_records += st1.n_records; total.kernel_ms += st1.kernel_ms; total.total_ms += st1.total_ms;
@@ -680,10 +709,10 @@ void device_trace(DeviceScene *D, const lrt_rays_soa *rays, const lrt_hits_soa *
         if (n) {
             if (D->use_lds) {                     // the render kernels' tracer: BVH image in LDS
                 const uint32_t g = std::min<uint32_t>((uint32_t) D->n_cus, (n + 1023) / 1024);
-                if (any_hit) k_trace_lds<true><<<g, 1024, D->lds.total_bytes, st>>>(D->sc, D->lds, ox, oy, oz, dx, dy, dz, tm, t, u, v, prim, n);
-                else k_trace_lds<false><<<g, 1024, D->lds.total_bytes, st>>>(D->sc, D->lds, ox, oy, oz, dx, dy, dz, tm, t, u, v, prim, n);
-            } else if (any_hit) k_trace<true><<<grid, LRT_BLOCK, 0, st>>>(D->sc, ox, oy, oz, dx, dy, dz, tm, t, u, v, prim, n);
-            else k_trace<false><<<grid, LRT_BLOCK, 0, st>>>(D->sc, ox, oy, oz, dx, dy, dz, tm, t, u, v, prim, n);
+                if (any_hit) k_trace_lds<true><<<g, 1024, D->lds.total_bytes, st>>>((ScenePtr) D->d_sc, D->lds, ox, oy, oz, dx, dy, dz, tm, t, u, v, prim, n);
+                else k_trace_lds<false><<<g, 1024, D->lds.total_bytes, st>>>((ScenePtr) D->d_sc, D->lds, ox, oy, oz, dx, dy, dz, tm, t, u, v, prim, n);
+            } else if (any_hit) k_trace<true><<<grid, LRT_BLOCK, 0, st>>>((ScenePtr) D->d_sc, ox, oy, oz, dx, dy, dz, tm, t, u, v, prim, n);
+            else k_trace<false><<<grid, LRT_BLOCK, 0, st>>>((ScenePtr) D->d_sc, ox, oy, oz, dx, dy, dz, tm, t, u, v, prim, n);
         }
         HIP_CHECK(hipMemcpyAsync(hits->t, t, (size_t) n * 4, hipMemcpyDeviceToHost, st));
         if (!any_hit) {
@@ -739,7 +768,8 @@ void device_render_backward(DeviceScene *D, const lrt_scene_desc &d, const lrt_r
         DRenderParams rw = make_params(d, O, all);
         for (uint64_t base = 0; base < all; base += (1ull << 30)) {
             const uint64_t n = std::min<uint64_t>(1ull << 30, all - base);
-            k_splat_lanes<true><<<(uint32_t) ((n + LRT_BLOCK - 1) / LRT_BLOCK), LRT_BLOCK, 0, st>>>(D->sc, rw, nullptr, nullptr, base, n, D->wfilm);
+            DLaunch a{}; a.rp = rw; a.lane_begin = base; a.n = n; a.film = D->wfilm;
+            k_splat_lanes<true><<<(uint32_t) ((n + LRT_BLOCK - 1) / LRT_BLOCK), LRT_BLOCK, 0, st>>>((ScenePtr) D->d_sc, push_launch(D, a));
         }
     }
     HIP_CHECK(hipMemsetAsync(D->d_grads, 0, 7 * sizeof(double), st));

@@ -113,6 +113,16 @@ struct DScene {
     DDistGrid grid;
 };
 
+// The scene record lives in device memory and is read through the CONSTANT address space: every `sc.field` is a scalar
+// load (s_load_dword*) issued where the value is used, instead of ~190 kernarg SGPRs that stay live through the whole
+// persistent kernel and are spilled to VGPR lanes (v_writelane / v_readlane: VALU work) - round-1 k_render: 347 SGPR spills.
+#define LRT_CONST __attribute__((address_space(4)))
+typedef const LRT_CONST DScene &SceneRef;
+typedef const LRT_CONST DFilm &FilmRef;
+typedef const LRT_CONST DEnv &EnvRef;
+typedef const LRT_CONST DDistGrid &GridRef;
+typedef const LRT_CONST DScene *ScenePtr;      // kernel argument (a plain device pointer on the host side)
+
 struct DRenderParams {
     int32_t integrator, max_depth, rr_depth, hide_emitters;
     uint32_t spp, log2_spp;    // log2_spp = 0xffffffff when spp is not a power of two
@@ -170,5 +180,17 @@ struct DLdsInfo {
     const uint4 *blob; const uint32_t *slot_prim;
     uint32_t blob_bytes, nodes_off, verts_off, tris_off, stack_off, total_bytes;
 };
+
+// Every argument of one launch of k_render / k_render_prb / k_splat_lanes, read through the constant address space like the
+// scene record (the host fills one slot of a small ring per launch, device.hip).
+struct DLaunch {
+    DRenderParams rp; DLdsInfo li; DPathStreams q0, q1;
+    float4 *dl0, *dl1;                    // PRB: delta_L streams
+    uint32_t P, pad; DCounters *cnt; const uint32_t *pixel_list; uint64_t lane_begin, n;
+    float4 *L_buf; const float *grad_image; const float *wfilm; double *grads;
+    float *film; float *sample_out; uint64_t sample_base;
+};
+typedef const LRT_CONST DRenderParams &RpRef;
+typedef const LRT_CONST DLaunch *LaunchPtr;
 
 } // namespace lrt

@@ -243,15 +243,15 @@ struct Frame {
 };
 
 // rows 0..2 of a row-major affine matrix stored as 12 floats
-DEV V3 xform_point12(const float *m, V3 p) {
+template <typename FP> DEV V3 xform_point12(FP m, V3 p) {      // FP: pointer to 12 floats in any address space
     return V3(fma_(m[2], p.z, fma_(m[1], p.y, fma_(m[0], p.x, m[3]))), fma_(m[6], p.z, fma_(m[5], p.y, fma_(m[4], p.x, m[7]))),
               fma_(m[10], p.z, fma_(m[9], p.y, fma_(m[8], p.x, m[11]))));
 }
-DEV V3 xform_vec12(const float *m, V3 v) {
+template <typename FP> DEV V3 xform_vec12(FP m, V3 v) {
     return V3(fma_(m[2], v.z, fma_(m[1], v.y, m[0] * v.x)), fma_(m[6], v.z, fma_(m[5], v.y, m[4] * v.x)),
               fma_(m[10], v.z, fma_(m[9], v.y, m[8] * v.x)));
 }
-DEV V3 xform_vec9(const float *m, V3 v) {
+template <typename FP> DEV V3 xform_vec9(FP m, V3 v) {
     return V3(fma_(m[2], v.z, fma_(m[1], v.y, m[0] * v.x)), fma_(m[5], v.z, fma_(m[4], v.y, m[3] * v.x)),
               fma_(m[8], v.z, fma_(m[7], v.y, m[6] * v.x)));
 }

@@ -40,7 +40,7 @@ DEV void test_tri(const float4 *__restrict__ tris, uint32_t slot, V3 o, V3 d, fl
 // Stack-based BVH2 traversal; the per-lane stack lives in LDS, laid out
 // [entry][thread] so that a wave's pushes/pops hit 64 consecutive banks.
 template <bool ANY_HIT>
-DEV Hit trace(const DScene &sc, const Ray &r, int *__restrict__ stack /* &lds[threadIdx.x] */) {
+DEV Hit trace(SceneRef sc, const Ray &r, int *__restrict__ stack /* &lds[threadIdx.x] */) {
     Hit best; best.t = kInf; best.u = best.v = 0.f; best.prim = 0xffffffffu;
     if (sc.n_faces == 0) return best;
     const V3 o = r.o, d = r.d;
@@ -93,7 +93,7 @@ DEV Hit trace(const DScene &sc, const Ray &r, int *__restrict__ stack /* &lds[th
 
 // Ray-query back-ends the integrator loops are templated on.
 struct GlobalTracer {                      // BVH in global memory (any scene size), 32-bit stack entries in LDS
-    const DScene &sc; int *stack;
+    SceneRef sc; int *stack;
     DEV Hit closest(const Ray &r) const { return trace<false>(sc, r, stack); }
     DEV Hit any(const Ray &r) const { return trace<true>(sc, r, stack); }
 };
@@ -195,7 +195,7 @@ struct LdsTracer {
 // --------------------------------------------------- conservative distance field
 // Lower bound of the distance from p to the nearest triangle (0: unknown / outside the grid).  |p - centre| is subtracted
 // exactly (1-Lipschitz), the stored value already carries the safety margins (device.hip: build_dist_grid).
-DEV float dist_grid_lower_bound(const DDistGrid &g, V3 p) {
+DEV float dist_grid_lower_bound(GridRef g, V3 p) {
     // D(c) - |p - c| bounds the distance for ANY p, so the cell index is simply clamped into the grid (a point outside the
     // grid gets a small or negative bound; NaN coordinates give NaN, which proves nothing).
     float fx = (p.x - g.lo[0]) * g.inv_cell, fy = (p.y - g.lo[1]) * g.inv_cell, fz = (p.z - g.lo[2]) * g.inv_cell;
@@ -212,7 +212,7 @@ DEV float dist_grid_lower_bound(const DDistGrid &g, V3 p) {
 #ifndef LRT_GRID_STEPS
 #define LRT_GRID_STEPS 3
 #endif
-DEV bool segment_proven_empty(const DDistGrid &g, V3 o, V3 d, float maxt) {
+DEV bool segment_proven_empty(GridRef g, V3 o, V3 d, float maxt) {
     if (!g.enabled || !(maxt < 1e30f)) return false;
     float len = __builtin_amdgcn_sqrtf(dot(d, d));                       // hardware sqrt / rcp (1 ulp): inside the margins
     float remaining = maxt * len * 1.01f, inv_len = __builtin_amdgcn_rcpf(len);
@@ -230,7 +230,7 @@ DEV bool segment_proven_empty(const DDistGrid &g, V3 o, V3 d, float maxt) {
 
 // --------------------------------------------------- surface interaction
 // src/render/mesh.cpp:1489-1659 + include/mitsuba/render/interaction.h:290-300,516-536
-DEV SI compute_si(const DScene &sc, const Ray &r, const Hit &h) {
+DEV SI compute_si(SceneRef sc, const Ray &r, const Hit &h) {
     const bool valid = h.prim != 0xffffffffu;
     // every field is written through plain locals (no member addresses escape): keeps the record in VGPRs
     float t = kInf; V3 p(0.f), n(0.f), shn(0.f), shs(0.f), sht(0.f), dp_du(0.f), dp_dv(0.f), wi = -r.d;
@@ -320,7 +320,7 @@ DEV V3 square_to_uniform_sphere(float sx, float sy) {
 }
 
 // -------------------------------------------------------------- textures
-DEV V3 tex_eval(const DScene &sc, int tex, const SI &si) {
+DEV V3 tex_eval(SceneRef sc, int tex, const SI &si) {
     const DTexture &T = sc.textures[tex];
     if (T.type == LRT_TEX_CHECKERBOARD) {        // src/textures/checkerboard.cpp:70-88
         float u = fma_(T.to_uv[1], si.uv.y, fma_(T.to_uv[0], si.uv.x, T.to_uv[2]));
@@ -334,7 +334,7 @@ DEV V3 tex_eval(const DScene &sc, int tex, const SI &si) {
 
 // src/textures/bitmap.cpp:509-578 eval_1_grad; texels hold the per-texel
 // luminance (precomputed on the host with the same float expression).
-DEV V2 tex_eval_1_grad(const DScene &sc, int tex, const SI &si) {
+DEV V2 tex_eval_1_grad(SceneRef sc, int tex, const SI &si) {
     const DTexture &T = sc.textures[tex];
     if (T.type != LRT_TEX_BITMAP) return { 0.f, 0.f };
     float u = fma_(T.to_uv[1], si.uv.y, fma_(T.to_uv[0], si.uv.x, T.to_uv[2]));
@@ -373,7 +373,7 @@ DEV void fresnel(float cos_theta_i, float eta, float *r, float *cos_theta_t, flo
 }
 
 // src/bsdfs/bumpmap.cpp:226-251
-DEV Frame bump_frame(const DScene &sc, const DBsdf &B, const SI &si) {
+DEV Frame bump_frame(SceneRef sc, const DBsdf &B, const SI &si) {
     V2 g = tex_eval_1_grad(sc, B.texture, si);
     float gx = B.scale * g.x, gy = B.scale * g.y;
     V3 dp_du = fma3(si.sh.n, gx - dot(si.sh.n, si.dp_du), si.dp_du);
@@ -394,7 +394,7 @@ DEV float shadow_terminator(V3 pn, V3 wo) {       // src/bsdfs/normalmap_helpers
 }
 
 // Leaf BSDFs (diffuse / dielectric / null), evaluated in the frame `wi` is given in.
-DEV BSDFSample leaf_sample(const DScene &sc, const DBsdf &B, const SI &si, V3 wi, float s1, float s2x, float s2y) {
+DEV BSDFSample leaf_sample(SceneRef sc, const DBsdf &B, const SI &si, V3 wi, float s1, float s2x, float s2y) {
     BSDFSample bs;
     bs.wo = V3(0.f); bs.pdf = 0.f; bs.eta = 0.f; bs.type = 0; bs.weight = V3(0.f);       // dr::zeros<BSDFSample3f>
     if (B.type == LRT_BSDF_DIFFUSE) {               // src/bsdfs/diffuse.cpp sample()
@@ -423,7 +423,7 @@ DEV BSDFSample leaf_sample(const DScene &sc, const DBsdf &B, const SI &si, V3 wi
     }
     return bs;
 }
-DEV V3 leaf_eval(const DScene &sc, const DBsdf &B, const SI &si, V3 wi, V3 wo) {
+DEV V3 leaf_eval(SceneRef sc, const DBsdf &B, const SI &si, V3 wi, V3 wo) {
     if (B.type == LRT_BSDF_DIFFUSE) {
         if (!(wi.z > 0.f && wo.z > 0.f)) return V3(0.f);
         return tex_eval(sc, B.reflectance, si) * kInvPi * wo.z;
@@ -435,7 +435,7 @@ DEV float leaf_pdf(const DBsdf &B, V3 wi, V3 wo) {
     return 0.f;
 }
 
-DEV BSDFSample bsdf_sample(const DScene &sc, int b, const SI &si, float s1, float s2x, float s2y) {
+DEV BSDFSample bsdf_sample(SceneRef sc, int b, const SI &si, float s1, float s2x, float s2y) {
     const DBsdf B = sc.bsdfs[b];
     if (B.type == LRT_BSDF_BUMPMAP) {               // src/bsdfs/bumpmap.cpp:138-162
         Frame pf = bump_frame(sc, B, si);
@@ -451,7 +451,7 @@ DEV BSDFSample bsdf_sample(const DScene &sc, int b, const SI &si, float s1, floa
     }
     return leaf_sample(sc, B, si, si.wi, s1, s2x, s2y);
 }
-DEV V3 bsdf_eval(const DScene &sc, int b, const SI &si, V3 wo) {
+DEV V3 bsdf_eval(SceneRef sc, int b, const SI &si, V3 wo) {
     const DBsdf B = sc.bsdfs[b];
     if (B.type == LRT_BSDF_BUMPMAP) {               // src/bsdfs/bumpmap.cpp:164-183
         Frame pf = bump_frame(sc, B, si);
@@ -461,7 +461,7 @@ DEV V3 bsdf_eval(const DScene &sc, int b, const SI &si, V3 wo) {
     }
     return leaf_eval(sc, B, si, si.wi, wo);
 }
-DEV float bsdf_pdf(const DScene &sc, int b, const SI &si, V3 wo) {
+DEV float bsdf_pdf(SceneRef sc, int b, const SI &si, V3 wo) {
     const DBsdf B = sc.bsdfs[b];
     if (B.type == LRT_BSDF_BUMPMAP) {
         Frame pf = bump_frame(sc, B, si);
@@ -471,7 +471,7 @@ DEV float bsdf_pdf(const DScene &sc, int b, const SI &si, V3 wo) {
     }
     return leaf_pdf(B, si.wi, wo);
 }
-DEV float bsdf_null_transmission(const DScene &sc, int b) { return sc.bsdfs[b].type == LRT_BSDF_NULL ? 1.f : 0.f; }
+DEV float bsdf_null_transmission(SceneRef sc, int b) { return sc.bsdfs[b].type == LRT_BSDF_NULL ? 1.f : 0.f; }
 
 // -------------------------------------------------------------- emitters
 struct DirSample { V3 p, n, d; float pdf, dist; bool delta; int emitter; };
@@ -482,8 +482,8 @@ DEV float interval_to_linear(float v0, float v1, float sample) {
         return (v0 - safe_sqrt(lerpf(sqr(v0), sqr(v1), sample))) / (v0 - v1);
     return sample;
 }
-DEV void hier_sample(const DScene &sc, float sx, float sy, float *ox, float *oy, float *pdf) {
-    const DEnv &E = sc.env;
+DEV void hier_sample(SceneRef sc, float sx, float sy, float *ox, float *oy, float *pdf) {
+    EnvRef E = sc.env;
     sx = clampf(sx, 0.f, 1.f); sy = clampf(sy, 0.f, 1.f);
     uint32_t offx = 0, offy = 0;
     for (int l = E.n_levels - 2; l > 0; --l) {
@@ -518,8 +518,8 @@ DEV void hier_sample(const DScene &sc, float sx, float sy, float *ox, float *oy,
     *oy = ((float) (int) offy + sy) * E.patch_size[1];
 }
 // include/mitsuba/core/distr_2d.h:695-726
-DEV float hier_eval(const DScene &sc, float px, float py) {
-    const DEnv &E = sc.env;
+DEV float hier_eval(SceneRef sc, float px, float py) {
+    EnvRef E = sc.env;
     px = clampf(px, 0.f, 1.f); py = clampf(py, 0.f, 1.f);
     px *= E.inv_patch_size[0]; py *= E.inv_patch_size[1];
     uint32_t ox = min((uint32_t) (int) px, E.max_patch[0]), oy = min((uint32_t) (int) py, E.max_patch[1]);
@@ -532,8 +532,8 @@ DEV float hier_eval(const DScene &sc, float px, float py) {
 }
 
 // src/emitters/envmap.cpp:528-560
-DEV V3 env_eval_uv(const DScene &sc, float u, float v) {
-    const DEnv &E = sc.env;
+DEV V3 env_eval_uv(SceneRef sc, float u, float v) {
+    EnvRef E = sc.env;
     uint32_t rx = E.w, ry = E.h;
     u -= .5f / (float) (rx - 1u);
     u -= __builtin_floorf(u); v -= __builtin_floorf(v);
@@ -550,8 +550,8 @@ DEV V3 env_eval_uv(const DScene &sc, float u, float v) {
     V3 vv(fma_(w0y, v0.x, t2.x), fma_(w0y, v0.y, t2.y), fma_(w0y, v0.z, t2.z));
     return vv * E.scale;
 }
-DEV V3 emitter_eval_env(const DScene &sc, V3 dir_world) {
-    const DEnv &E = sc.env;
+DEV V3 emitter_eval_env(SceneRef sc, V3 dir_world) {
+    EnvRef E = sc.env;
     if (E.type == LRT_EMITTER_CONSTANT) return V3(E.radiance[0], E.radiance[1], E.radiance[2]);
     V3 v = xform_vec9(E.to_local, dir_world);           // src/emitters/envmap.cpp:353-362
     float uu = m_atan2(v.x, -v.z) * kInvTwoPi, vv = safe_acos(v.y) * kInvPi;
@@ -559,7 +559,7 @@ DEV V3 emitter_eval_env(const DScene &sc, V3 dir_world) {
 }
 
 // Scene::sample_emitter_direction without visibility test (src/render/scene.cpp:333-383)
-DEV V3 sample_emitter_direction(const DScene &sc, V3 ref_p, float sx, float sy, DirSample *ds) {
+DEV V3 sample_emitter_direction(SceneRef sc, V3 ref_p, float sx, float sy, DirSample *ds) {
     uint32_t ne = sc.n_emitters;
     ds->p = V3(0.f); ds->n = V3(0.f); ds->d = V3(0.f); ds->pdf = 0.f; ds->dist = 0.f; ds->delta = false; ds->emitter = -1;
     if (ne == 0) return V3(0.f);
@@ -587,7 +587,7 @@ DEV V3 sample_emitter_direction(const DScene &sc, V3 ref_p, float sx, float sy, 
         V3 rad(E.radiance[0], E.radiance[1], E.radiance[2]);
         spec = active ? rad / ds->pdf : V3(0.f);
     } else if (E.type == LRT_EMITTER_ENVMAP) {          // src/emitters/envmap.cpp:415-459
-        const DEnv &EV = sc.env;
+        EnvRef EV = sc.env;
         float u, v, pdf; hier_sample(sc, sx, sy, &u, &v, &pdf);
         u += .5f / (float) (EV.w - 1u);
         bool active = pdf > 0.f;
@@ -605,7 +605,7 @@ DEV V3 sample_emitter_direction(const DScene &sc, V3 ref_p, float sx, float sy, 
         V3 val = env_eval_uv(sc, u, v);
         spec = active ? val / ds->pdf : V3(0.f);
     } else {                                            // src/emitters/constant.cpp sample_direction
-        const DEnv &EV = sc.env;
+        EnvRef EV = sc.env;
         V3 d = square_to_uniform_sphere(sx, sy);
         V3 c(EV.bsphere_c[0], EV.bsphere_c[1], EV.bsphere_c[2]);
         float radius = fmax_(EV.bsphere_r, norm(ref_p - c)), dist = 2.f * radius;
@@ -619,7 +619,7 @@ DEV V3 sample_emitter_direction(const DScene &sc, V3 ref_p, float sx, float sy, 
 
 // DirectionSample(scene, si, ref) + Scene::pdf_emitter_direction
 // (include/mitsuba/render/records.h:173-180, src/render/scene.cpp:395-406)
-DEV float pdf_emitter_direction(const DScene &sc, V3 ref_p, const SI &si, int emitter) {
+DEV float pdf_emitter_direction(SceneRef sc, V3 ref_p, const SI &si, int emitter) {
     V3 rel = si.p - ref_p;
     float dist = norm(rel);
     V3 d = si.valid ? rel / dist : -si.wi;
@@ -632,7 +632,7 @@ DEV float pdf_emitter_direction(const DScene &sc, V3 ref_p, const SI &si, int em
         float adp = __builtin_fabsf(dp);
         value = E.inv_area * (adp != 0.f ? (dist * dist) / adp : 0.f);
     } else if (E.type == LRT_EMITTER_ENVMAP) {          // src/emitters/envmap.cpp:461-475
-        const DEnv &EV = sc.env;
+        EnvRef EV = sc.env;
         V3 dl = xform_vec9(EV.to_local, d);
         float u = m_atan2(dl.x, -dl.z) * kInvTwoPi, v = safe_acos(dl.y) * kInvPi;
         u -= .5f / (float) (EV.w - 1u);
@@ -643,8 +643,8 @@ DEV float pdf_emitter_direction(const DScene &sc, V3 ref_p, const SI &si, int em
     return value * pmf;
 }
 
-DEV int si_emitter(const DScene &sc, const SI &si) { return si.valid ? sc.shapes[si.shape].emitter : sc.env.emitter; }
-DEV V3 emitter_eval(const DScene &sc, int e, const SI &si) {
+DEV int si_emitter(SceneRef sc, const SI &si) { return si.valid ? sc.shapes[si.shape].emitter : sc.env.emitter; }
+DEV V3 emitter_eval(SceneRef sc, int e, const SI &si) {
     if (!si.valid) return emitter_eval_env(sc, -si.wi);
     const DEmitter &E = sc.emitters[e];                 // src/emitters/area.cpp eval()
     return (si.wi.z > 0.f) ? V3(E.radiance[0], E.radiance[1], E.radiance[2]) : V3(0.f);

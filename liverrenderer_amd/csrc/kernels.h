@@ -45,7 +45,7 @@ DEV void store_state(const DPathStreams &q, uint32_t i, const PathState &s) {
 // lane) seeds the PCG32 stream (sampler.cpp:129-148); ld: the sequence is the lane's pixel, scramble seed =
 // TEA4(base, spp * pixel + seed).first (sampler.cpp:97-107), sample index = lane % spp (:109-117).
 template <bool LD>
-DEV uint64_t lane_rng_inc(const DRenderParams &rp, uint32_t lane) {
+DEV uint64_t lane_rng_inc(RpRef rp, uint32_t lane) {
     if (LD) {
         const uint32_t pixel = (rp.log2_spp != 0xffffffffu) ? (lane >> rp.log2_spp) : (lane / rp.spp);
         uint32_t v0, v1; tea32(rp.base_seed, rp.spp * pixel + rp.seed, &v0, &v1);
@@ -55,18 +55,18 @@ DEV uint64_t lane_rng_inc(const DRenderParams &rp, uint32_t lane) {
     return ((uint64_t) v1 << 1) | 1u;
 }
 template <bool LD>
-DEV SamplerT<LD> lane_rng_fresh(const DRenderParams &rp, uint32_t lane) {
+DEV SamplerT<LD> lane_rng_fresh(RpRef rp, uint32_t lane) {
     SamplerT<LD> r; r.ld_count = rp.ld_count;
     if (LD) { r.state = 0; r.inc = lane_rng_inc<LD>(rp, lane); return r; }
     uint32_t v0, v1; tea32(rp.seed_value, lane, &v0, &v1);
     r.seed(v0, v1); return r;
 }
 template <bool LD>
-DEV SamplerT<LD> lane_rng_resume(const DRenderParams &rp, uint32_t lane, uint64_t state) {
+DEV SamplerT<LD> lane_rng_resume(RpRef rp, uint32_t lane, uint64_t state) {
     SamplerT<LD> r; r.ld_count = rp.ld_count; r.state = state; r.inc = lane_rng_inc<LD>(rp, lane); return r;
 }
 // Rank-local index of a lane within the current pass (the index space of per-lane buffers)
-DEV uint64_t lane_local_index(const DRenderParams &rp, uint32_t lane) {
+DEV uint64_t lane_local_index(RpRef rp, uint32_t lane) {
     if (!rp.pixel_slot) return lane;
     const uint32_t pixel = (rp.log2_spp != 0xffffffffu) ? (lane >> rp.log2_spp) : (lane / rp.spp);
     return (uint64_t) rp.pixel_slot[pixel] * rp.spp + (lane - pixel * rp.spp);
@@ -74,20 +74,20 @@ DEV uint64_t lane_local_index(const DRenderParams &rp, uint32_t lane) {
 // The sampler of a lane at the start of the current pass: freshly seeded in pass 0; in later passes the independent sampler
 // continues from the state its path of the previous pass left (Sampler::advance() does not reseed), index j = rank-local lane.
 template <bool LD>
-DEV SamplerT<LD> lane_rng_pass_start(const DRenderParams &rp, uint32_t lane, uint64_t j) {
+DEV SamplerT<LD> lane_rng_pass_start(RpRef rp, uint32_t lane, uint64_t j) {
     SamplerT<LD> r = lane_rng_fresh<LD>(rp, lane);
     if (!LD && rp.pass_index > 0) r.state = rp.pass_in[j];
     return r;
 }
 // the pixel jitter: the sampler's first 2-D sample of the pass (integrator.cpp:465), needed again wherever a film footprint is formed
-DEV void lane_jitter(const DRenderParams &rp, uint32_t lane, uint64_t j, float &jx, float &jy) {
+DEV void lane_jitter(RpRef rp, uint32_t lane, uint64_t j, float &jx, float &jy) {
     if (rp.ld_count) { SamplerT<true> r = lane_rng_pass_start<true>(rp, lane, j); r.next2(jx, jy); }
     else { SamplerT<false> r = lane_rng_pass_start<false>(rp, lane, j); r.next2(jx, jy); }
 }
 
 // lane -> pixel (src/render/integrator.cpp:321-338); tile-sharded renders go
 // through the rank's pixel list so that seeding uses the GLOBAL lane index.
-DEV void lane_to_pixel(const DScene &sc, const DRenderParams &rp, uint32_t lane, int *px, int *py) {
+DEV void lane_to_pixel(SceneRef sc, RpRef rp, uint32_t lane, int *px, int *py) {
     uint32_t idx = (rp.log2_spp != 0xffffffffu) ? (lane >> rp.log2_spp) : (lane / rp.spp);
     uint32_t W = (uint32_t) sc.film.width;
     uint32_t y = idx / W, x = idx - y * W;
@@ -95,8 +95,8 @@ DEV void lane_to_pixel(const DScene &sc, const DRenderParams &rp, uint32_t lane,
 }
 
 // src/sensors/perspective.cpp:239-279
-DEV Ray camera_ray(const DScene &sc, float ax, float ay) {
-    const float *m = sc.cam.s2c;
+DEV Ray camera_ray(SceneRef sc, float ax, float ay) {
+    const LRT_CONST float *m = sc.cam.s2c;
     V3 p(ax + sc.cam.ppo_x, ay + sc.cam.ppo_y, 0.f);
     float r[4];
 #pragma unroll
@@ -115,7 +115,7 @@ DEV Ray camera_ray(const DScene &sc, float ax, float ay) {
 // A fresh camera path for rank-local lane index j (integrator.cpp:321-338,449-470; volpath.cpp:93-140 /
 // path.cpp:95-170 up to the loop).
 template <bool LD>
-DEV PathState generate_camera_path(const DScene &sc, const DRenderParams &rp, const uint32_t *__restrict__ pixel_list, uint64_t j) {
+DEV PathState generate_camera_path(SceneRef sc, RpRef rp, const uint32_t *__restrict__ pixel_list, uint64_t j) {
     uint32_t lane;
     if (pixel_list) { uint32_t pj = (uint32_t) (j / rp.spp); lane = pixel_list[pj] * rp.spp + (uint32_t) (j - (uint64_t) pj * rp.spp); }
     else lane = (uint32_t) j;
@@ -142,14 +142,14 @@ DEV PathState generate_camera_path(const DScene &sc, const DRenderParams &rp, co
 }
 
 // ------------------------------------------------------------------ film
-DEV float estrin10(float x, const float *c) {
+template <typename FP> DEV float estrin10(float x, FP c) {
     float x2 = x * x, x4 = x2 * x2, x8 = x4 * x4;
     float a0 = fma_(x, c[1], c[0]), a1 = fma_(x, c[3], c[2]), a2 = fma_(x, c[5], c[4]), a3 = fma_(x, c[7], c[6]), a4 = fma_(x, c[9], c[8]);
     float b0 = fma_(x2, a1, a0), b1 = fma_(x2, a3, a2);
     float c0 = fma_(x4, b1, b0);
     return fma_(x8, a4, c0);
 }
-DEV float rfilter_eval(const DFilm &F, float x) {
+DEV float rfilter_eval(FilmRef F, float x) {
     if (F.rfilter == LRT_RFILTER_GAUSSIAN) return fmax_(estrin10(sqr(x), F.rf_coeff), 0.f);
     if (F.rfilter == LRT_RFILTER_TENT) return fmax_(0.f, 1.f - __builtin_fabsf(x * F.rf_inv_radius));
     return (__builtin_fabsf(x) <= 0.5f) ? 1.f : 0.f;
@@ -157,7 +157,7 @@ DEV float rfilter_eval(const DFilm &F, float x) {
 
 // A finished path: splat {R,G,B,[A],W=1} (integrator.cpp:499-520, imageblock.cpp:174-232,431-500),
 // or, for the per-lane test hook, store the radiance.
-DEV void finish_path(const DScene &sc, const DRenderParams &rp, float *__restrict__ film, float *__restrict__ sample_out,
+DEV void finish_path(SceneRef sc, RpRef rp, float *__restrict__ film, float *__restrict__ sample_out,
                      uint64_t sample_base, uint32_t lane, V3 L, bool valid) {
     if (rp.integrator == LRT_INTEGRATOR_PATH && !valid) L = V3(0.f);                 // path.cpp:342-345
     if (sample_out) {                               // per-lane output, indexed by the rank-local lane index
@@ -166,7 +166,7 @@ DEV void finish_path(const DScene &sc, const DRenderParams &rp, float *__restric
         *o = make_float4(L.x, L.y, L.z, valid ? 1.f : 0.f);
         return;
     }
-    const DFilm &F = sc.film;
+    FilmRef F = sc.film;
     int px, py; lane_to_pixel(sc, rp, lane, &px, &py);
     const int C = F.channels;
     const float alpha = valid ? 1.f : 0.f;
@@ -203,9 +203,9 @@ DEV void finish_path(const DScene &sc, const DRenderParams &rp, float *__restric
 // Film accumulation called by EVERY lane of a wave (`finishing` selects the lanes that retire a path).  Box filter:
 // lanes that splat into the same pixel are summed inside the wave first (the wavefront keeps a pixel's samples in
 // neighbouring lanes, so a wave usually holds one or two distinct pixels) and one lane issues the atomics.
-DEV void finish_paths_wave(const DScene &sc, const DRenderParams &rp, float *__restrict__ film, float *__restrict__ sample_out,
+DEV void finish_paths_wave(SceneRef sc, RpRef rp, float *__restrict__ film, float *__restrict__ sample_out,
                            uint64_t sample_base, bool finishing, uint32_t lane, V3 L, bool valid) {
-    const DFilm &F = sc.film;
+    FilmRef F = sc.film;
     if (sample_out || F.rfilter != LRT_RFILTER_BOX) {
         if (finishing) finish_path(sc, rp, film, sample_out, sample_base, lane, L, valid);
         return;
@@ -251,7 +251,7 @@ DEV void finish_paths_wave(const DScene &sc, const DRenderParams &rp, float *__r
 // ---------------------------------------------------------- volpath NEE
 // src/integrators/volpath.cpp:400-554.  ref_n is zero for medium interactions.
 template <typename SMP, typename TR>
-DEV V3 volpath_sample_emitter(const DScene &sc, SMP &rng, V3 ref_p, V3 ref_n, bool ref_is_surface, uint32_t ref_shape, V3 ref_geo_n,
+DEV V3 volpath_sample_emitter(SceneRef sc, SMP &rng, V3 ref_p, V3 ref_n, bool ref_is_surface, uint32_t ref_shape, V3 ref_geo_n,
                               int medium, uint32_t channel, DirSample *ds_out, const TR &tr, uint32_t &n_shadow) {
     V3 transmittance(1.f);
     float sx, sy; rng.next2(sx, sy);
@@ -323,7 +323,7 @@ DEV V3 volpath_sample_emitter(const DScene &sc, SMP &rng, V3 ref_p, V3 ref_n, bo
 // One trip of volpath's while_loop (src/integrators/volpath.cpp:170-391).
 // Returns true when the path survives.
 template <typename SMP, typename TR>
-DEV bool volpath_iteration(const DScene &sc, const DRenderParams &rp, PathState &s, SMP &rng, const TR &tr, uint32_t &n_shadow, uint32_t &n_extra) {
+DEV bool volpath_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, const TR &tr, uint32_t &n_shadow, uint32_t &n_extra) {
     uint32_t depth = s.flags & PF_DEPTH_MASK;
     const bool proven_empty = (s.flags & PF_NOHIT) != 0;
     int medium = (int) ((s.flags & PF_MEDIUM_MASK) >> PF_MEDIUM_SHIFT) - 1;
@@ -521,7 +521,7 @@ DEV bool volpath_iteration(const DScene &sc, const DRenderParams &rp, PathState 
 // ray_intersect_preliminary of the previous trip (:332-337, or :164-169 for the
 // first one) is the trace at the top.
 template <typename SMP, typename TR>
-DEV bool path_iteration(const DScene &sc, const DRenderParams &rp, PathState &s, SMP &rng, const TR &tr, uint32_t &n_shadow) {
+DEV bool path_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, const TR &tr, uint32_t &n_shadow) {
     uint32_t depth = s.flags & PF_DEPTH_MASK;
     bool prev_bsdf_delta = (s.flags & PF_SPECULAR) != 0, valid_ray = (s.flags & PF_VALID) != 0;
     const uint32_t max_depth = (uint32_t) rp.max_depth;
@@ -628,13 +628,13 @@ namespace lrt {
 //   B  2P-1-j, j < n_b     paths outside media
 // n_a + n_b + n_c <= P, so the regions never collide.  No cross-workgroup dependency exists besides the lane ticket and the
 // film atomics; every wave leaves its loops once the ticket is exhausted and its pool is empty.
-DEV DPathStreams offset_streams(const DPathStreams &q, size_t off) {
+template <typename QS> DEV DPathStreams offset_streams(const QS &q, size_t off) {
     DPathStreams r; r.o_maxt = q.o_maxt + off; r.d_eta = q.d_eta + off; r.tp_pdf = q.tp_pdf + off; r.res_flags = q.res_flags + off; r.lp_lane = q.lp_lane + off; r.rng = q.rng + off; r.tdepth = q.tdepth + off;
     return r;
 }
 
 template <bool BIO = false>
-DEV void retire_and_compact_wave(const DScene &sc, const DRenderParams &rp, bool had_path, bool alive, const PathState &s,
+DEV void retire_and_compact_wave(SceneRef sc, RpRef rp, bool had_path, bool alive, const PathState &s,
                                  float *__restrict__ film, float *__restrict__ sample_out, uint64_t sample_base,
                                  const DPathStreams &qout, uint32_t P, uint32_t *s_out /* LDS [3] */) {
     const uint32_t lane_in_wave = threadIdx.x & 63u;
@@ -658,8 +658,12 @@ DEV void retire_and_compact_wave(const DScene &sc, const DRenderParams &rp, bool
 // 4 waves per SIMD for every variant (128 VGPRs): one 1024-thread workgroup per CU, or four 256-thread ones
 template <int INTEGRATOR, int BLOCK, bool LDS_BVH, bool LD>
 __global__ void __launch_bounds__(BLOCK, 4)
-k_render(DScene sc, DRenderParams rp, DLdsInfo li, DPathStreams q0, DPathStreams q1, uint32_t P, DCounters *__restrict__ cnt,
-         const uint32_t *__restrict__ pixel_list, uint64_t lane_begin, float *__restrict__ film, float *__restrict__ sample_out, uint64_t sample_base) {
+k_render(ScenePtr scp, LaunchPtr lp) {
+    SceneRef sc = *scp;
+    const LRT_CONST DLaunch &A = *lp;                          // launch arguments: scalar loads where they are used
+    RpRef rp = A.rp;
+    const LRT_CONST DLdsInfo &li = A.li;
+    const uint32_t P = A.P;
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ uint32_t s_in[3], s_out[3], s_ticket, s_fresh;
     __shared__ unsigned long long s_fresh_base, s_prof[8];
@@ -677,7 +681,7 @@ k_render(DScene sc, DRenderParams rp, DLdsInfo li, DPathStreams q0, DPathStreams
     const LdsTracer<BLOCK> tr_lds{ L, reinterpret_cast<uint16_t *>(smem + li.stack_off) + tid };
     const GlobalTracer tr_glb{ sc, reinterpret_cast<int *>(smem) + tid };
     const size_t pool = (size_t) blockIdx.x * 2u * P;
-    DPathStreams qin = offset_streams(q0, pool), qout = offset_streams(q1, pool);
+    DPathStreams qin = offset_streams(A.q0, pool), qout = offset_streams(A.q1, pool);
     if (tid == 0) { s_in[0] = s_in[1] = s_in[2] = 0; }
     bool lanes_left = true;                                   // thread 0
     uint32_t n_shadow = 0, n_extra = 0, n_trips = 0, n_loaded = 0;
@@ -686,7 +690,7 @@ k_render(DScene sc, DRenderParams rp, DLdsInfo li, DPathStreams q0, DPathStreams
             const uint32_t want = P - (s_in[0] + s_in[1] + s_in[2]);
             uint32_t got = 0; unsigned long long base = 0;
             if (want && lanes_left) {
-                base = atomicAdd(&cnt->next_lane, (unsigned long long) want);
+                base = atomicAdd(&A.cnt->next_lane, (unsigned long long) want);
                 if (base < rp.n_lanes) got = (uint32_t) (rp.n_lanes - base < (unsigned long long) want ? rp.n_lanes - base : (unsigned long long) want);
                 lanes_left = base + want < rp.n_lanes;
             }
@@ -715,7 +719,7 @@ k_render(DScene sc, DRenderParams rp, DLdsInfo li, DPathStreams q0, DPathStreams
             } else {
                 const uint32_t i = ((t - ta - tc - tb) << 6) + lane_in_wave;
                 had_path = i < fresh;
-                if (had_path) s = generate_camera_path<LD>(sc, rp, pixel_list, lane_begin + fresh_base + i);
+                if (had_path) s = generate_camera_path<LD>(sc, rp, A.pixel_list, A.lane_begin + fresh_base + i);
             }
 #ifdef LRT_EXPERIMENT
             const PathState s_saved = s;
@@ -752,7 +756,7 @@ k_render(DScene sc, DRenderParams rp, DLdsInfo li, DPathStreams q0, DPathStreams
                 }
             }
 #endif
-            retire_and_compact_wave<BIO>(sc, rp, had_path, alive, s, film, sample_out, sample_base, qout, P, s_out);
+            retire_and_compact_wave<BIO>(sc, rp, had_path, alive, s, A.film, A.sample_out, A.sample_base, qout, P, s_out);
             if ((rp.profile & 1u) && lane_in_wave == 0) {
                 const int region = t < ta ? 0 : (t < ta + tc ? 1 : (t < ta + tc + tb ? 2 : 3));
                 atomicAdd(&s_prof[region], wall_clock64() - t_begin); atomicAdd(&s_prof[4 + region], 1ull);
@@ -762,15 +766,15 @@ k_render(DScene sc, DRenderParams rp, DLdsInfo li, DPathStreams q0, DPathStreams
         if (tid == 0) { s_in[0] = s_out[0]; s_in[1] = s_out[1]; s_in[2] = s_out[2]; }
         const DPathStreams tmp = qin; qin = qout; qout = tmp;
     }
-    if ((rp.profile & 1u) && tid < 8) { if (tid < 4) atomicAdd(&cnt->prof_cycles[tid], s_prof[tid]); else atomicAdd(&cnt->prof_tiles[tid - 4], s_prof[tid]); }
+    if ((rp.profile & 1u) && tid < 8) { if (tid < 4) atomicAdd(&A.cnt->prof_cycles[tid], s_prof[tid]); else atomicAdd(&A.cnt->prof_tiles[tid - 4], s_prof[tid]); }
     n_trips += n_extra;
     for (int off = 32; off > 0; off >>= 1) {
         n_shadow += __shfl_down(n_shadow, off); n_trips += __shfl_down(n_trips, off); n_loaded += __shfl_down(n_loaded, off);
     }
     if (lane_in_wave == 0) {
-        if (n_shadow) atomicAdd(&cnt->n_shadow, (unsigned long long) n_shadow);
-        if (n_trips) atomicAdd(&cnt->n_iter, (unsigned long long) n_trips);
-        if (n_loaded) atomicAdd(&cnt->n_records, (unsigned long long) n_loaded);
+        if (n_shadow) atomicAdd(&A.cnt->n_shadow, (unsigned long long) n_shadow);
+        if (n_trips) atomicAdd(&A.cnt->n_iter, (unsigned long long) n_trips);
+        if (n_loaded) atomicAdd(&A.cnt->n_records, (unsigned long long) n_loaded);
     }
 }
 
@@ -827,9 +831,13 @@ k_build_dist_grid(const float4 *__restrict__ tris, uint32_t n_slots, DDistGrid g
 // common.py:730-746); lane_L is not read.
 template <bool WEIGHTS_ONLY>
 __global__ void __launch_bounds__(LRT_BLOCK)
-k_splat_lanes(DScene sc, DRenderParams rp, const float4 *__restrict__ lane_L, const uint32_t *__restrict__ pixel_list, uint64_t slot_base, uint64_t n,
-              float *__restrict__ film) {
-    const DFilm &F = sc.film;
+k_splat_lanes(ScenePtr scp, LaunchPtr lp) {
+    RpRef rp = lp->rp;
+    const float4 *__restrict__ lane_L = lp->L_buf; const uint32_t *__restrict__ pixel_list = lp->pixel_list;
+    const uint64_t slot_base = lp->lane_begin, n = lp->n;
+    float *__restrict__ film = lp->film;
+    SceneRef sc = *scp;
+    FilmRef F = sc.film;
     const uint64_t i = (uint64_t) blockIdx.x * LRT_BLOCK + threadIdx.x;
     const uint32_t me = threadIdx.x & 63u;
     const bool have = i < n;
@@ -903,8 +911,9 @@ __global__ void k_develop(DFilm F, const float *__restrict__ film, float *__rest
 
 template <bool ANY_HIT>
 __global__ void __launch_bounds__(LRT_BLOCK)
-k_trace(DScene sc, const float *ox, const float *oy, const float *oz, const float *dx, const float *dy, const float *dz, const float *tmax,
+k_trace(ScenePtr scp, const float *ox, const float *oy, const float *oz, const float *dx, const float *dy, const float *dz, const float *tmax,
         float *t, float *u, float *v, uint32_t *prim, uint32_t n) {
+    SceneRef sc = *scp;
     __shared__ int s_stack[LRT_STACK * LRT_BLOCK];
     uint32_t i = blockIdx.x * LRT_BLOCK + threadIdx.x;
     if (i >= n) return;
@@ -917,8 +926,9 @@ k_trace(DScene sc, const float *ox, const float *oy, const float *oz, const floa
 // The same queries through the LDS-resident BVH image (1024 threads per workgroup, as in k_render)
 template <bool ANY_HIT>
 __global__ void __launch_bounds__(1024)
-k_trace_lds(DScene sc, DLdsInfo li, const float *ox, const float *oy, const float *oz, const float *dx, const float *dy, const float *dz, const float *tmax,
+k_trace_lds(ScenePtr scp, DLdsInfo li, const float *ox, const float *oy, const float *oz, const float *dx, const float *dy, const float *dz, const float *tmax,
             float *t, float *u, float *v, uint32_t *prim, uint32_t n) {
+    SceneRef sc = *scp;
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t tid = threadIdx.x;
     {

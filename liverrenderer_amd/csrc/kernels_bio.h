@@ -77,7 +77,7 @@ DEV BioMI bio_sample_interaction(const DBioMedium &B, V3 o, V3 d, float maxt, fl
 
 // biovolpath.cpp:383-541 sample_emitter (surface reference points only)
 template <typename SMP, typename TR>
-DEV V3 bio_sample_emitter(const DScene &sc, SMP &rng, V3 ref_p, V3 ref_n, uint32_t ref_shape, int medium, uint32_t channel, float tissue_depth,
+DEV V3 bio_sample_emitter(SceneRef sc, SMP &rng, V3 ref_p, V3 ref_n, uint32_t ref_shape, int medium, uint32_t channel, float tissue_depth,
                           DirSample *ds_out, const TR &tr, uint32_t &n_shadow) {
     V3 transmittance(1.f);
     float sx, sy; rng.next2(sx, sy);
@@ -141,7 +141,7 @@ DEV V3 bio_sample_emitter(const DScene &sc, SMP &rng, V3 ref_p, V3 ref_n, uint32
 // One trip of biovolpath's while_loop (biovolpath.cpp:177-374), JIT-variant lane semantics.  s.si_t carries the distance
 // the previous trip's ray query returned (`Ray3f(ray, si.t)` at :226), s.tdepth the loop state `tissueDepth`.
 template <typename SMP, typename TR>
-DEV bool biovolpath_iteration(const DScene &sc, const DRenderParams &rp, PathState &s, SMP &rng, const TR &tr, uint32_t &n_shadow) {
+DEV bool biovolpath_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, const TR &tr, uint32_t &n_shadow) {
     uint32_t depth = s.flags & PF_DEPTH_MASK;
     int medium = (int) ((s.flags & PF_MEDIUM_MASK) >> PF_MEDIUM_SHIFT) - 1;
     const uint32_t channel = (s.flags >> PF_CHANNEL_SHIFT) & 3u;
@@ -274,7 +274,7 @@ DEV bool biovolpath_iteration(const DScene &sc, const DRenderParams &rp, PathSta
 // 0x27e, 0x27f or 0x1, i.e. two facts: PF_BIO_EMIT = (type & 0x0001), PF_BIO_FULL = (type & 0x0004) = (type & 0x0008).
 // No sampler call is skipped: scalar code executes only the calls it reaches.
 template <typename SMP, typename TR>
-DEV bool biovolpath06_iteration(const DScene &sc, const DRenderParams &rp, PathState &s, SMP &rng, const TR &tr) {
+DEV bool biovolpath06_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, const TR &tr) {
     uint32_t depth = s.flags & PF_DEPTH_MASK;
     int medium = (int) ((s.flags & PF_MEDIUM_MASK) >> PF_MEDIUM_SHIFT) - 1;
     const uint32_t channel = (s.flags >> PF_CHANNEL_SHIFT) & 3u;

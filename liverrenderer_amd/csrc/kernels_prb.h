@@ -24,7 +24,7 @@ DEV float hg_dlog_dg(float g, float c) {
 // prbvolpath.py:354-444.  Returns emitter_val * transmittance; seg_sum[c] accumulates -t_seg * scale over the
 // medium segments the reference backpropagates through (segments that end on a surface with tr_c > 0, :425-427).
 template <typename SMP, typename TR>
-DEV V3 prb_sample_emitter(const DScene &sc, SMP &rng, V3 ref_p, V3 ref_n, bool ref_is_surface, uint32_t ref_shape, V3 ref_geo_n,
+DEV V3 prb_sample_emitter(SceneRef sc, SMP &rng, V3 ref_p, V3 ref_n, bool ref_is_surface, uint32_t ref_shape, V3 ref_geo_n,
                           int medium, uint32_t channel, DirSample *ds_out, const TR &tr, uint32_t &n_shadow, V3 *seg_sum, int grad_medium) {
     float sx, sy; rng.next2(sx, sy);
     DirSample ds; V3 emitter_val = sample_emitter_direction(sc, ref_p, sx, sy, &ds);
@@ -79,7 +79,7 @@ DEV V3 prb_sample_emitter(const DScene &sc, SMP &rng, V3 ref_p, V3 ref_n, bool r
 // One trip of prbvolpath's loop (prbvolpath.py:139-349).  s.res holds L: accumulated radiance (primal) or the
 // radiance still to be collected (adjoint).  Returns true when the path survives.
 template <bool ADJOINT, typename SMP, typename TR>
-DEV bool prb_iteration(const DScene &sc, const DRenderParams &rp, PathState &s, SMP &rng, const TR &tr, uint32_t &n_shadow,
+DEV bool prb_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, const TR &tr, uint32_t &n_shadow,
                        V3 delta_L, PrbGrads &G) {
     uint32_t depth = s.flags & PF_DEPTH_MASK;
     const bool proven_empty = (s.flags & PF_NOHIT) != 0;               // look-ahead of the previous trip, see below
@@ -249,7 +249,7 @@ DEV bool prb_iteration(const DScene &sc, const DRenderParams &rp, PathState &s, 
 }
 
 // Filter footprint helpers shared by the weight-film and delta_L kernels (imageblock.cpp:431-500)
-DEV void lane_sample_pos(const DScene &sc, const DRenderParams &rp, uint32_t lane, float *spx, float *spy, int *px, int *py) {
+DEV void lane_sample_pos(SceneRef sc, RpRef rp, uint32_t lane, float *spx, float *spy, int *px, int *py) {
     lane_to_pixel(sc, rp, lane, px, py);
     float jx, jy; lane_jitter(rp, lane, lane_local_index(rp, lane), jx, jy);
     *spx = (float) *px + jx; *spy = (float) *py + jy;
@@ -257,8 +257,8 @@ DEV void lane_sample_pos(const DScene &sc, const DRenderParams &rp, uint32_t lan
 
 // delta_L of a lane: gradient of sum(image * grad_image) w.r.t. the lane's radiance through splat + develop
 // (common.py:730-746).  Box filter: grad[pixel] / W[pixel].
-DEV V3 lane_delta_L(const DScene &sc, const DRenderParams &rp, uint32_t lane, const float *__restrict__ grad_image, const float *__restrict__ wfilm) {
-    const DFilm &F = sc.film;
+DEV V3 lane_delta_L(SceneRef sc, RpRef rp, uint32_t lane, const float *__restrict__ grad_image, const float *__restrict__ wfilm) {
+    FilmRef F = sc.film;
     const int T = F.has_alpha ? 4 : 3;
     if (F.rfilter == LRT_RFILTER_BOX) {
         int px, py; lane_to_pixel(sc, rp, lane, &px, &py);
@@ -296,10 +296,13 @@ DEV V3 lane_delta_L(const DScene &sc, const DRenderParams &rp, uint32_t lane, co
 // 4 waves per SIMD for every variant (128 VGPRs): one 1024-thread workgroup per CU, or four 256-thread ones
 template <bool ADJOINT, int BLOCK, bool LDS_BVH, bool LD>
 __global__ void __launch_bounds__(BLOCK, 4)
-k_render_prb(DScene sc, DRenderParams rp, DLdsInfo li, DPathStreams q0, DPathStreams q1, float4 *__restrict__ dl0, float4 *__restrict__ dl1, uint32_t P,
-             DCounters *__restrict__ cnt, const uint32_t *__restrict__ pixel_list, uint64_t lane_begin,
-             float4 *__restrict__ L_buf, const float *__restrict__ grad_image, const float *__restrict__ wfilm, double *__restrict__ grads,
-             float *__restrict__ film, float *__restrict__ sample_out, uint64_t sample_base) {
+k_render_prb(ScenePtr scp, LaunchPtr lp) {
+    SceneRef sc = *scp;
+    const LRT_CONST DLaunch &A = *lp;
+    RpRef rp = A.rp;
+    const LRT_CONST DLdsInfo &li = A.li;
+    const uint32_t P = A.P;
+    float4 *__restrict__ L_buf = A.L_buf; const float *__restrict__ grad_image = A.grad_image; const float *__restrict__ wfilm = A.wfilm;
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ uint32_t s_in[3], s_out[3], s_ticket, s_fresh;
     __shared__ unsigned long long s_fresh_base;
@@ -316,8 +319,8 @@ k_render_prb(DScene sc, DRenderParams rp, DLdsInfo li, DPathStreams q0, DPathStr
     const LdsTracer<BLOCK> tr_lds{ L, reinterpret_cast<uint16_t *>(smem + li.stack_off) + tid };
     const GlobalTracer tr_glb{ sc, reinterpret_cast<int *>(smem) + tid };
     const size_t pool = (size_t) blockIdx.x * 2u * P;
-    DPathStreams qin = offset_streams(q0, pool), qout = offset_streams(q1, pool);
-    float4 *dlin = dl0 + pool, *dlout = dl1 + pool;
+    DPathStreams qin = offset_streams(A.q0, pool), qout = offset_streams(A.q1, pool);
+    float4 *dlin = A.dl0 + pool, *dlout = A.dl1 + pool;
     if (tid == 0) { s_in[0] = s_in[1] = s_in[2] = 0; }
     if (tid < 7) s_grad[tid] = 0.0;
     bool lanes_left = true;                                   // thread 0
@@ -327,7 +330,7 @@ k_render_prb(DScene sc, DRenderParams rp, DLdsInfo li, DPathStreams q0, DPathStr
             const uint32_t want = P - (s_in[0] + s_in[1] + s_in[2]);
             uint32_t got = 0; unsigned long long base = 0;
             if (want && lanes_left) {
-                base = atomicAdd(&cnt->next_lane, (unsigned long long) want);
+                base = atomicAdd(&A.cnt->next_lane, (unsigned long long) want);
                 if (base < rp.n_lanes) got = (uint32_t) (rp.n_lanes - base < (unsigned long long) want ? rp.n_lanes - base : (unsigned long long) want);
                 lanes_left = base + want < rp.n_lanes;
             }
@@ -359,7 +362,7 @@ k_render_prb(DScene sc, DRenderParams rp, DLdsInfo li, DPathStreams q0, DPathStr
                 had_path = i < fresh;
                 if (had_path) {                                // common.py:231-309 + prbvolpath.py:113-137
                     const unsigned long long slot = fresh_base + i;
-                    s = generate_camera_path<LD>(sc, rp, pixel_list, lane_begin + slot);
+                    s = generate_camera_path<LD>(sc, rp, A.pixel_list, A.lane_begin + slot);
                     s.flags = PF_SPECULAR | (s.flags & (3u << PF_CHANNEL_SHIFT));      // valid_ray = false, specular_chain = true, medium = none
                     V3 dL(0.f);
                     if (ADJOINT) { float4 l = L_buf[slot]; s.res = V3(l.x, l.y, l.z); dL = lane_delta_L(sc, rp, s.lane, grad_image, wfilm); }
@@ -376,7 +379,7 @@ k_render_prb(DScene sc, DRenderParams rp, DLdsInfo li, DPathStreams q0, DPathStr
             }
             if (!ADJOINT) {
                 if (L_buf) { if (had_path && !alive) L_buf[f2u(dl.w)] = make_float4(s.res.x, s.res.y, s.res.z, (s.flags & PF_VALID) ? 1.f : 0.f); }
-                else finish_paths_wave(sc, rp, film, sample_out, sample_base, had_path && !alive, s.lane, s.res, (s.flags & PF_VALID) != 0);
+                else finish_paths_wave(sc, rp, A.film, A.sample_out, A.sample_base, had_path && !alive, s.lane, s.res, (s.flags & PF_VALID) != 0);
             } else {
                 float g[7] = { G.sigma_t[0], G.sigma_t[1], G.sigma_t[2], G.albedo[0], G.albedo[1], G.albedo[2], G.g };
 #pragma unroll
@@ -403,14 +406,14 @@ k_render_prb(DScene sc, DRenderParams rp, DLdsInfo li, DPathStreams q0, DPathStr
         const DPathStreams tmp = qin; qin = qout; qout = tmp;
         float4 *tdl = dlin; dlin = dlout; dlout = tdl;
     }
-    if (ADJOINT && tid < 7 && s_grad[tid] != 0.0) atomicAdd(&grads[tid], s_grad[tid]);
+    if (ADJOINT && tid < 7 && s_grad[tid] != 0.0) atomicAdd(&A.grads[tid], s_grad[tid]);
     for (int off = 32; off > 0; off >>= 1) {
         n_shadow += __shfl_down(n_shadow, off); n_trips += __shfl_down(n_trips, off); n_loaded += __shfl_down(n_loaded, off);
     }
     if (lane_in_wave == 0) {
-        if (n_shadow) atomicAdd(&cnt->n_shadow, (unsigned long long) n_shadow);
-        if (n_trips) atomicAdd(&cnt->n_iter, (unsigned long long) n_trips);
-        if (n_loaded) atomicAdd(&cnt->n_records, (unsigned long long) n_loaded);
+        if (n_shadow) atomicAdd(&A.cnt->n_shadow, (unsigned long long) n_shadow);
+        if (n_trips) atomicAdd(&A.cnt->n_iter, (unsigned long long) n_trips);
+        if (n_loaded) atomicAdd(&A.cnt->n_records, (unsigned long long) n_loaded);
     }
 }
 
