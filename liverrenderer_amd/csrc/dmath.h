@@ -27,6 +27,8 @@ static constexpr float kLargest = 3.402823466e+38f;
 #define kInf __builtin_inff()
 
 DEV float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+DEV f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }   // v_pk_fma_f32 on gfx950
 DEV uint32_t f2u(float f) { return __float_as_uint(f); }
 DEV float u2f(uint32_t u) { return __uint_as_float(u); }
 DEV float sqr(float x) { return x * x; }

@@ -56,6 +56,7 @@ DEV Hit trace(SceneRef sc, const Ray &r, int *__restrict__ stack /* &lds[threadI
     // inf - inf = NaN, so that rays parallel to a slab are kept or culled by the side of the origin (the padding decides ties)
     const float ix = slab_rcp(d.x), iy = slab_rcp(d.y), iz = slab_rcp(d.z);
     const float ox = -o.x * ix, oy = -o.y * iy, oz = -o.z * iz;
+    const f32x2 vix = { ix, ix }, viy = { iy, iy }, viz = { iz, iz }, vox = { ox, ox }, voy = { oy, oy }, voz = { oz, oz };
     const uint32_t DONE = 0x7fffffffu;
     int sp = 0; uint32_t cur = 0;
     for (;;) {
@@ -63,8 +64,11 @@ DEV Hit trace(SceneRef sc, const Ray &r, int *__restrict__ stack /* &lds[threadI
             const float4 *nd = sc.nodes + 4 * (size_t) cur;
             float4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3];
             float limit = fmin_(best.t, r.maxt);
-            float ax0 = fma_(n0.x, ix, ox), ax1 = fma_(n0.y, ix, ox), ay0 = fma_(n0.z, iy, oy), ay1 = fma_(n0.w, iy, oy), az0 = fma_(n2.x, iz, oz), az1 = fma_(n2.y, iz, oz);
-            float bx0 = fma_(n1.x, ix, ox), bx1 = fma_(n1.y, ix, ox), by0 = fma_(n1.z, iy, oy), by1 = fma_(n1.w, iy, oy), bz0 = fma_(n2.z, iz, oz), bz1 = fma_(n2.w, iz, oz);
+            // twelve slab planes as six packed fmas (v_pk_fma_f32: both halves in one issue slot; IEEE fma per element)
+            const f32x2 vax = pk_fma(f32x2{ n0.x, n0.y }, vix, vox), vay = pk_fma(f32x2{ n0.z, n0.w }, viy, voy), vaz = pk_fma(f32x2{ n2.x, n2.y }, viz, voz);
+            const f32x2 vbx = pk_fma(f32x2{ n1.x, n1.y }, vix, vox), vby = pk_fma(f32x2{ n1.z, n1.w }, viy, voy), vbz = pk_fma(f32x2{ n2.z, n2.w }, viz, voz);
+            const float ax0 = vax.x, ax1 = vax.y, ay0 = vay.x, ay1 = vay.y, az0 = vaz.x, az1 = vaz.y;
+            const float bx0 = vbx.x, bx1 = vbx.y, by0 = vby.x, by1 = vby.y, bz0 = vbz.x, bz1 = vbz.y;
             float tmin0 = fmax_(fmax_(fmin_(ax0, ax1), fmin_(ay0, ay1)), fmax_(fmin_(az0, az1), 0.f));
             float tmax0 = fmin_(fmin_(fmax_(ax0, ax1), fmax_(ay0, ay1)), fmin_(fmax_(az0, az1), limit));
             float tmin1 = fmax_(fmax_(fmin_(bx0, bx1), fmin_(by0, by1)), fmax_(fmin_(bz0, bz1), 0.f));
@@ -147,6 +151,7 @@ DEV Hit trace_lds(const LdsScene &L, const Ray &r, uint16_t *__restrict__ stack 
     // inf - inf = NaN, so that rays parallel to a slab are kept or culled by the side of the origin (the padding decides ties)
     const float ix = slab_rcp(d.x), iy = slab_rcp(d.y), iz = slab_rcp(d.z);
     const float ox = -o.x * ix, oy = -o.y * iy, oz = -o.z * iz;
+    const f32x2 vix = { ix, ix }, viy = { iy, iy }, viz = { iz, iz }, vox = { ox, ox }, voy = { oy, oy }, voz = { oz, oz };
     const uint32_t DONE = 0x10000u;
     int sp = 0; uint32_t cur = 0;
     for (;;) {
@@ -154,8 +159,11 @@ DEV Hit trace_lds(const LdsScene &L, const Ray &r, uint16_t *__restrict__ stack 
             const float4 *nd = L.nodes + 4 * cur;
             float4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3];
             float limit = fmin_(best.t, r.maxt);
-            float ax0 = fma_(n0.x, ix, ox), ax1 = fma_(n0.y, ix, ox), ay0 = fma_(n0.z, iy, oy), ay1 = fma_(n0.w, iy, oy), az0 = fma_(n2.x, iz, oz), az1 = fma_(n2.y, iz, oz);
-            float bx0 = fma_(n1.x, ix, ox), bx1 = fma_(n1.y, ix, ox), by0 = fma_(n1.z, iy, oy), by1 = fma_(n1.w, iy, oy), bz0 = fma_(n2.z, iz, oz), bz1 = fma_(n2.w, iz, oz);
+            // twelve slab planes as six packed fmas (v_pk_fma_f32: both halves in one issue slot; IEEE fma per element)
+            const f32x2 vax = pk_fma(f32x2{ n0.x, n0.y }, vix, vox), vay = pk_fma(f32x2{ n0.z, n0.w }, viy, voy), vaz = pk_fma(f32x2{ n2.x, n2.y }, viz, voz);
+            const f32x2 vbx = pk_fma(f32x2{ n1.x, n1.y }, vix, vox), vby = pk_fma(f32x2{ n1.z, n1.w }, viy, voy), vbz = pk_fma(f32x2{ n2.z, n2.w }, viz, voz);
+            const float ax0 = vax.x, ax1 = vax.y, ay0 = vay.x, ay1 = vay.y, az0 = vaz.x, az1 = vaz.y;
+            const float bx0 = vbx.x, bx1 = vbx.y, by0 = vby.x, by1 = vby.y, bz0 = vbz.x, bz1 = vbz.y;
             float tmin0 = fmax_(fmax_(fmin_(ax0, ax1), fmin_(ay0, ay1)), fmax_(fmin_(az0, az1), 0.f));
             float tmax0 = fmin_(fmin_(fmax_(ax0, ax1), fmax_(ay0, ay1)), fmin_(fmax_(az0, az1), limit));
             float tmin1 = fmax_(fmax_(fmin_(bx0, bx1), fmin_(by0, by1)), fmax_(fmin_(bz0, bz1), 0.f));

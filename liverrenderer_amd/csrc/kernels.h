@@ -22,16 +22,16 @@ struct PathState {
 
 // BIO: a queued path's ray always comes from spawn_ray (maxt = largest float), so its maxt slot carries si_t instead, and
 // the seventh stream holds tissueDepth (92 B records)
-template <bool BIO = false>
-DEV void load_state(const DPathStreams &q, uint32_t i, PathState &s) {
+template <bool BIO = false, typename QS>
+DEV void load_state(const QS &q, size_t i, PathState &s) {
     float4 a = q.o_maxt[i], b = q.d_eta[i], c = q.tp_pdf[i], d = q.res_flags[i], e = q.lp_lane[i]; uint2 r = q.rng[i];
     s.o = V3(a.x, a.y, a.z); s.maxt = a.w; s.d = V3(b.x, b.y, b.z); s.eta = b.w;
     s.tp = V3(c.x, c.y, c.z); s.last_pdf = c.w; s.res = V3(d.x, d.y, d.z); s.flags = f2u(d.w);
     s.lp = V3(e.x, e.y, e.z); s.lane = f2u(e.w); s.rng_state = ((uint64_t) r.y << 32) | r.x;
     if (BIO) { s.si_t = a.w; s.maxt = kLargest; s.tdepth = q.tdepth[i]; }
 }
-template <bool BIO = false>
-DEV void store_state(const DPathStreams &q, uint32_t i, const PathState &s) {
+template <bool BIO = false, typename QS>
+DEV void store_state(const QS &q, size_t i, const PathState &s) {
     q.o_maxt[i] = make_float4(s.o.x, s.o.y, s.o.z, BIO ? s.si_t : s.maxt);
     q.d_eta[i] = make_float4(s.d.x, s.d.y, s.d.z, s.eta);
     q.tp_pdf[i] = make_float4(s.tp.x, s.tp.y, s.tp.z, s.last_pdf);
@@ -636,7 +636,7 @@ template <typename QS> DEV DPathStreams offset_streams(const QS &q, size_t off) 
 template <bool BIO = false>
 DEV void retire_and_compact_wave(SceneRef sc, RpRef rp, bool had_path, bool alive, const PathState &s,
                                  float *__restrict__ film, float *__restrict__ sample_out, uint64_t sample_base,
-                                 const DPathStreams &qout, uint32_t P, uint32_t *s_out /* LDS [3] */) {
+                                 const LRT_CONST DPathStreams &qout, size_t pool, uint32_t P, uint32_t *s_out /* LDS [3] */) {
     const uint32_t lane_in_wave = threadIdx.x & 63u;
     finish_paths_wave(sc, rp, film, sample_out, sample_base, had_path && !alive, s.lane, s.res, (s.flags & PF_VALID) != 0);
     if (rp.pass_out && had_path && !alive) rp.pass_out[lane_local_index(rp, s.lane)] = s.rng_state;       // next pass continues this stream
@@ -651,7 +651,7 @@ DEV void retire_and_compact_wave(SceneRef sc, RpRef rp, bool had_path, bool aliv
     if (alive) {
         const unsigned long long mine = region == 0 ? m0 : (region == 1 ? m1 : m2);
         const uint32_t slot = b + (uint32_t) __popcll(mine & ((1ull << lane_in_wave) - 1ull));
-        store_state<BIO>(qout, region == 0 ? slot : (region == 1 ? P + slot : 2u * P - 1u - slot), s);
+        store_state<BIO>(qout, pool + (region == 0 ? slot : (region == 1 ? P + slot : 2u * P - 1u - slot)), s);
     }
 }
 
@@ -681,7 +681,7 @@ k_render(ScenePtr scp, LaunchPtr lp) {
     const LdsTracer<BLOCK> tr_lds{ L, reinterpret_cast<uint16_t *>(smem + li.stack_off) + tid };
     const GlobalTracer tr_glb{ sc, reinterpret_cast<int *>(smem) + tid };
     const size_t pool = (size_t) blockIdx.x * 2u * P;
-    DPathStreams qin = offset_streams(A.q0, pool), qout = offset_streams(A.q1, pool);
+    uint32_t parity = 0;                                      // queue the round reads: parity ? A.q1 : A.q0 (the stream pointers are scalar loads at the point of use)
     if (tid == 0) { s_in[0] = s_in[1] = s_in[2] = 0; }
     bool lanes_left = true;                                   // thread 0
     uint32_t n_shadow = 0, n_extra = 0, n_trips = 0, n_loaded = 0;
@@ -715,7 +715,7 @@ k_render(ScenePtr scp, LaunchPtr lp) {
                 if (t < ta) { i = (t << 6) + lane_in_wave; had_path = i < n_a; }
                 else if (t < ta + tc) { i = ((t - ta) << 6) + lane_in_wave; had_path = i < n_c; i += P; }
                 else { i = ((t - ta - tc) << 6) + lane_in_wave; had_path = i < n_b; i = 2u * P - 1u - i; }
-                if (had_path) { load_state<BIO>(qin, i, s); n_loaded += 1; }
+                if (had_path) { load_state<BIO>(parity ? A.q1 : A.q0, pool + i, s); n_loaded += 1; }
             } else {
                 const uint32_t i = ((t - ta - tc - tb) << 6) + lane_in_wave;
                 had_path = i < fresh;
@@ -735,7 +735,7 @@ k_render(ScenePtr scp, LaunchPtr lp) {
             if (had_path) {
                 SamplerT<LD> rng = lane_rng_resume<LD>(rp, s.lane, s.rng_state);
                 if (INTEGRATOR == LRT_INTEGRATOR_PATH) alive = LDS_BVH ? path_iteration(sc, rp, s, rng, tr_lds, n_shadow) : path_iteration(sc, rp, s, rng, tr_glb, n_shadow);
-                else if (INTEGRATOR == LRT_INTEGRATOR_BIOVOLPATH) alive = LDS_BVH ? biovolpath_iteration(sc, rp, s, rng, tr_lds, n_shadow) : biovolpath_iteration(sc, rp, s, rng, tr_glb, n_shadow);
+                else if (INTEGRATOR == LRT_INTEGRATOR_BIOVOLPATH) alive = LDS_BVH ? biovolpath_iteration(sc, rp, s, rng, tr_lds, n_shadow, n_extra) : biovolpath_iteration(sc, rp, s, rng, tr_glb, n_shadow, n_extra);
                 else if (INTEGRATOR == LRT_INTEGRATOR_BIOVOLPATH06) alive = LDS_BVH ? biovolpath06_iteration(sc, rp, s, rng, tr_lds) : biovolpath06_iteration(sc, rp, s, rng, tr_glb);
                 else alive = LDS_BVH ? volpath_iteration(sc, rp, s, rng, tr_lds, n_shadow, n_extra) : volpath_iteration(sc, rp, s, rng, tr_glb, n_shadow, n_extra);
                 s.rng_state = rng.state;
@@ -756,7 +756,7 @@ k_render(ScenePtr scp, LaunchPtr lp) {
                 }
             }
 #endif
-            retire_and_compact_wave<BIO>(sc, rp, had_path, alive, s, A.film, A.sample_out, A.sample_base, qout, P, s_out);
+            retire_and_compact_wave<BIO>(sc, rp, had_path, alive, s, A.film, A.sample_out, A.sample_base, parity ? A.q0 : A.q1, pool, P, s_out);
             if ((rp.profile & 1u) && lane_in_wave == 0) {
                 const int region = t < ta ? 0 : (t < ta + tc ? 1 : (t < ta + tc + tb ? 2 : 3));
                 atomicAdd(&s_prof[region], wall_clock64() - t_begin); atomicAdd(&s_prof[4 + region], 1ull);
@@ -764,7 +764,7 @@ k_render(ScenePtr scp, LaunchPtr lp) {
         }
         __syncthreads();
         if (tid == 0) { s_in[0] = s_out[0]; s_in[1] = s_out[1]; s_in[2] = s_out[2]; }
-        const DPathStreams tmp = qin; qin = qout; qout = tmp;
+        parity ^= 1u;
     }
     if ((rp.profile & 1u) && tid < 8) { if (tid < 4) atomicAdd(&A.cnt->prof_cycles[tid], s_prof[tid]); else atomicAdd(&A.cnt->prof_tiles[tid - 4], s_prof[tid]); }
     n_trips += n_extra;

@@ -141,8 +141,9 @@ DEV V3 bio_sample_emitter(SceneRef sc, SMP &rng, V3 ref_p, V3 ref_n, uint32_t re
 // One trip of biovolpath's while_loop (biovolpath.cpp:177-374), JIT-variant lane semantics.  s.si_t carries the distance
 // the previous trip's ray query returned (`Ray3f(ray, si.t)` at :226), s.tdepth the loop state `tissueDepth`.
 template <typename SMP, typename TR>
-DEV bool biovolpath_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, const TR &tr, uint32_t &n_shadow) {
+DEV bool biovolpath_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, const TR &tr, uint32_t &n_shadow, uint32_t &n_extra) {
     uint32_t depth = s.flags & PF_DEPTH_MASK;
+    const bool proven_empty = (s.flags & PF_NOHIT) != 0;               // look-ahead of the previous trip (below)
     int medium = (int) ((s.flags & PF_MEDIUM_MASK) >> PF_MEDIUM_SHIFT) - 1;
     const uint32_t channel = (s.flags >> PF_CHANNEL_SHIFT) & 3u;
     bool specular_chain = (s.flags & PF_SPECULAR) != 0, valid_ray = (s.flags & PF_VALID) != 0;
@@ -177,7 +178,7 @@ DEV bool biovolpath_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, con
         const DBioMedium &B = sc.bio[medium];
         mei = bio_sample_interaction<true>(B, ray.o, ray.d, si_t, rng.next(), channel, tissue_depth);
         if (mei.valid()) ray.maxt = mei.t;
-        { Hit h = tr.closest(ray); si = compute_si(sc, ray, h); }
+        if (!proven_empty) { Hit h = tr.closest(ray); si = compute_si(sc, ray, h); }   // else: no surface within mei.t, the query returns "none"
         si_t = si.t;
         if (si.t < mei.t) mei.t = kInf;
         if (B.has_spectral_extinction) {                                // Medium::transmittance_eval_pdf (medium.cpp:92-104)
@@ -264,7 +265,26 @@ DEV bool biovolpath_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, con
         if (is_medium_transition(sd)) medium = target_medium(sd, ray.d, si.n);
     }
     active = active && (active_surface || active_medium);
+    // ---- look-ahead into the next trip, as in volpath_iteration (exact: the same draws on a copy of the generator).
+    // (1) A path the next trip's termination test would stop is retired now, with the cleared result that trip leaves
+    // (JIT reading of :200-208 + :297-300); the trip is counted in n_extra.  (2) In a medium the next free-flight sample is
+    // known: when the competition places an interaction inside the surface distance and the distance field proves the
+    // segment free of surfaces, the path is queued in region A and skips its ray query.
+    uint32_t nohit = 0;
+    if (active) {
+        SMP pk = rng;
+        bool a2 = any_nonzero(throughput);
+        float q2 = fmin_(max3(throughput) * sqr(eta), .95f);
+        if (a2) { float u = pk.next(); a2 = (u < q2) || !(depth > (uint32_t) rp.rr_depth); }
+        a2 = a2 && depth < max_depth;
+        if (!a2) { active = false; n_extra += 1; rng = pk; result = V3(0.f); }
+        else if (medium >= 0 && sc.grid.enabled) {
+            const BioMI m2 = bio_sample_interaction<true>(sc.bio[medium], ray.o, ray.d, si_t, pk.next(), channel, tissue_depth);
+            if (m2.valid() && segment_proven_empty(sc.grid, ray.o, ray.d, m2.t)) nohit = PF_NOHIT;
+        }
+    }
     commit();
+    s.flags |= nohit;
     return active;
 }
 

@@ -319,8 +319,7 @@ k_render_prb(ScenePtr scp, LaunchPtr lp) {
     const LdsTracer<BLOCK> tr_lds{ L, reinterpret_cast<uint16_t *>(smem + li.stack_off) + tid };
     const GlobalTracer tr_glb{ sc, reinterpret_cast<int *>(smem) + tid };
     const size_t pool = (size_t) blockIdx.x * 2u * P;
-    DPathStreams qin = offset_streams(A.q0, pool), qout = offset_streams(A.q1, pool);
-    float4 *dlin = A.dl0 + pool, *dlout = A.dl1 + pool;
+    uint32_t parity = 0;                                      // queue the round reads: parity ? q1 : q0 (scalar loads at the point of use)
     if (tid == 0) { s_in[0] = s_in[1] = s_in[2] = 0; }
     if (tid < 7) s_grad[tid] = 0.0;
     bool lanes_left = true;                                   // thread 0
@@ -356,7 +355,7 @@ k_render_prb(ScenePtr scp, LaunchPtr lp) {
                 if (t < ta) { i = (t << 6) + lane_in_wave; had_path = i < n_a; }
                 else if (t < tm) { i = ((t - ta) << 6) + lane_in_wave; had_path = i < n_c; i += P; }
                 else { i = ((t - tm) << 6) + lane_in_wave; had_path = i < n_s; i = 2u * P - 1u - i; }
-                if (had_path) { load_state(qin, i, s); dl = dlin[i]; n_loaded += 1; }
+                if (had_path) { load_state(parity ? A.q1 : A.q0, pool + i, s); dl = (parity ? A.dl1 : A.dl0)[pool + i]; n_loaded += 1; }
             } else {
                 const uint32_t i = ((t - tm - ts) << 6) + lane_in_wave;
                 had_path = i < fresh;
@@ -398,13 +397,12 @@ k_render_prb(ScenePtr scp, LaunchPtr lp) {
             if (alive) {
                 const uint32_t slot = b + (uint32_t) __popcll((region == 0 ? m0 : (region == 1 ? m1 : m2)) & ((1ull << lane_in_wave) - 1ull));
                 const uint32_t rec = region == 0 ? slot : (region == 1 ? P + slot : 2u * P - 1u - slot);
-                store_state(qout, rec, s); dlout[rec] = dl;
+                store_state(parity ? A.q0 : A.q1, pool + rec, s); (parity ? A.dl0 : A.dl1)[pool + rec] = dl;
             }
         }
         __syncthreads();
         if (tid == 0) { s_in[0] = s_out[0]; s_in[1] = s_out[1]; s_in[2] = s_out[2]; }
-        const DPathStreams tmp = qin; qin = qout; qout = tmp;
-        float4 *tdl = dlin; dlin = dlout; dlout = tdl;
+        parity ^= 1u;
     }
     if (ADJOINT && tid < 7 && s_grad[tid] != 0.0) atomicAdd(&A.grads[tid], s_grad[tid]);
     for (int off = 32; off > 0; off >>= 1) {
