@@ -50,10 +50,12 @@ typedef enum {
 
 /* ---------------------------------------------------------------- enums */
 enum { LRT_INTEGRATOR_PATH = 0, LRT_INTEGRATOR_VOLPATH = 1, LRT_INTEGRATOR_PRBVOLPATH = 2,
+       LRT_INTEGRATOR_VOLPATHMIS = 5,    /* src/integrators/volpathmis.cpp (spectral MIS)                 */
        LRT_INTEGRATOR_BIOVOLPATH = 3,    /* src/integrators/biovolpath.cpp, JIT-variant lane semantics   */
        LRT_INTEGRATOR_BIOVOLPATH06 = 4   /* src/integrators/biovolpath06.cpp, scalar semantics per lane   */ };
 /* medium plugins: src/media/homogeneous.cpp, liver.cpp, parenchyma.cpp, glissonCapsule.cpp (docs/BIO_TRANSPORT_SPEC.md) */
-enum { LRT_MEDIUM_HOMOGENEOUS = 0, LRT_MEDIUM_LIVER = 1, LRT_MEDIUM_PARENCHYMA = 2, LRT_MEDIUM_GLISSON = 3 };
+enum { LRT_MEDIUM_HOMOGENEOUS = 0, LRT_MEDIUM_LIVER = 1, LRT_MEDIUM_PARENCHYMA = 2, LRT_MEDIUM_GLISSON = 3,
+       LRT_MEDIUM_HETEROGENEOUS = 4   /* src/media/heterogeneous.cpp: sigma_t from a grid volume, delta tracking */ };
 enum { LRT_BSDF_DIFFUSE = 0, LRT_BSDF_DIELECTRIC = 1, LRT_BSDF_BUMPMAP = 2, LRT_BSDF_NULL = 3 };
 enum { LRT_TEX_RGB = 0, LRT_TEX_CHECKERBOARD = 1, LRT_TEX_BITMAP = 2 };
 enum { LRT_PHASE_ISOTROPIC = 0, LRT_PHASE_HG = 1 };
@@ -119,6 +121,13 @@ typedef struct {
     float   sigma_elastin[4][3];   /* layers 1-2 swapped the same way, layers 3-4 not (liver.cpp:168-186) */
     float   sigma_blood[3], sigma_bile[3], sigma_lipid_water[3];   /* liver / parenchyma                 */
     float   sigma_hepatocity;
+    /* --- heterogeneous medium: sigma_t = scale * gridvolume (src/volumes/grid.cpp: one channel, trilinear, clamp), albedo
+       constant; majorant = scale * grid_max.  The 4-argument sample_interaction of src/render/medium.cpp:40-82.        */
+    int32_t grid_res[3];      /* x, y, z; all 0 when there is no grid                */
+    float   grid_to_local[12];/* world -> the grid's unit cube [0,1]^3, rows 0..2 (Volume::m_to_local)            */
+    float   grid_bbox_min[3], grid_bbox_max[3];   /* world-space bounds of that cube (Volume::update_bbox)       */
+    float   grid_max;         /* maximum of the grid values (Volume::max)            */
+    const float *grid_data;   /* x fastest: data[(z * res_y + y) * res_x + x]         */
 } lrt_medium_desc;
 
 typedef struct {

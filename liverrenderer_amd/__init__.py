@@ -14,7 +14,7 @@ from . import _lib
 from ._lib import make_opts
 
 __all__ = ["set_variant", "variant", "variants", "load_file", "load_string", "load_dict", "cornell_box", "render",
-           "traverse", "Scene", "ScalarTransform4f", "render_stats", "Bitmap", "Struct", "util", "read_image", "write_exr", "write_png"]
+           "traverse", "Scene", "ScalarTransform4f", "render_stats", "write_volume_grid", "Bitmap", "Struct", "util", "read_image", "write_exr", "write_png"]
 
 _VARIANT = "hip_ad_rgb"
 
@@ -114,12 +114,13 @@ def cornell_box():
 # ------------------------------------------------------------- dict -> XML
 _TAGS = {
     "scene": "scene", "path": "integrator", "volpath": "integrator", "prbvolpath": "integrator",
-    "biovolpath": "integrator", "biovolpath06": "integrator",
+    "biovolpath": "integrator", "biovolpath06": "integrator", "volpathmis": "integrator",
     "perspective": "sensor", "independent": "sampler", "ldsampler": "sampler", "hdrfilm": "film",
     "box": "rfilter", "gaussian": "rfilter", "tent": "rfilter",
     "diffuse": "bsdf", "dielectric": "bsdf", "bumpmap": "bsdf", "null": "bsdf",
     "bitmap": "texture", "checkerboard": "texture",
-    "homogeneous": "medium", "liver": "medium", "parenchyma": "medium", "glissonCapsule": "medium",
+    "homogeneous": "medium", "liver": "medium", "parenchyma": "medium", "glissonCapsule": "medium", "heterogeneous": "medium",
+    "gridvolume": "volume",
     "isotropic": "phase", "hg": "phase",
     "obj": "shape", "rectangle": "shape", "cube": "shape",
     "area": "emitter", "envmap": "emitter", "constant": "emitter",
@@ -348,6 +349,19 @@ class SceneParameters(dict):
 
 def traverse(scene):
     return SceneParameters(scene)
+
+
+def write_volume_grid(path, data, bbox_min=(0.0, 0.0, 0.0), bbox_max=(1.0, 1.0, 1.0)):
+    """mi.VolumeGrid(array).write(path) (src/render/volumegrid.cpp:94-118): a one-channel float32 grid, array shape
+    (res_z, res_y, res_x), as the version-3 ".vol" file `gridvolume` reads."""
+    import struct
+    a = np.ascontiguousarray(data, dtype=np.float32)
+    if a.ndim != 3:
+        raise ValueError("write_volume_grid: expected an array of shape (res_z, res_y, res_x)")
+    with open(path, "wb") as f:
+        f.write(b"VOL" + struct.pack("<B", 3) + struct.pack("<iiiii", 1, a.shape[2], a.shape[1], a.shape[0], 1))
+        f.write(struct.pack("<6f", *bbox_min, *bbox_max))
+        f.write(a.tobytes())
 
 
 def _defines(kw):

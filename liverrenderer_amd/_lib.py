@@ -11,8 +11,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LRT_LIBRARY") or os.path.join(_HERE, "libliverrt.so")     # LRT_LIBRARY: developer builds (csrc/Makefile: exp)
 
 OK = 0
-INTEGRATOR = {"path": 0, "volpath": 1, "prbvolpath": 2, "biovolpath": 3, "biovolpath06": 4}
-MEDIUM = {"homogeneous": 0, "liver": 1, "parenchyma": 2, "glissonCapsule": 3}
+INTEGRATOR = {"path": 0, "volpath": 1, "prbvolpath": 2, "biovolpath": 3, "biovolpath06": 4, "volpathmis": 5}
+MEDIUM = {"homogeneous": 0, "liver": 1, "parenchyma": 2, "glissonCapsule": 3, "heterogeneous": 4}
 
 
 class ShapeDesc(C.Structure):
@@ -39,7 +39,10 @@ class MediumDesc(C.Structure):
                 # bio media (liver / parenchyma / glissonCapsule): include/liverrt.h
                 ("type", C.c_int32), ("layer_limit", C.c_float * 4), ("sigma_collagen", (C.c_float * 3) * 4),
                 ("sigma_elastin", (C.c_float * 3) * 4), ("sigma_blood", C.c_float * 3), ("sigma_bile", C.c_float * 3),
-                ("sigma_lipid_water", C.c_float * 3), ("sigma_hepatocity", C.c_float)]
+                ("sigma_lipid_water", C.c_float * 3), ("sigma_hepatocity", C.c_float),
+                # heterogeneous medium (grid volume)
+                ("grid_res", C.c_int32 * 3), ("grid_to_local", C.c_float * 12), ("grid_bbox_min", C.c_float * 3),
+                ("grid_bbox_max", C.c_float * 3), ("grid_max", C.c_float), ("grid_data", C.POINTER(C.c_float))]
 
 
 class EmitterDesc(C.Structure):

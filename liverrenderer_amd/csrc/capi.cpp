@@ -88,7 +88,8 @@ static void validate_desc(const lrt_scene_desc &d) {
     }
     for (uint32_t i = 0; i < d.n_media; ++i) {
         const lrt_medium_desc &M = d.media[i];
-        if (M.type < LRT_MEDIUM_HOMOGENEOUS || M.type > LRT_MEDIUM_GLISSON) bad("invalid medium type");
+        if (M.type < LRT_MEDIUM_HOMOGENEOUS || M.type > LRT_MEDIUM_HETEROGENEOUS) bad("invalid medium type");
+        if (M.type == LRT_MEDIUM_HETEROGENEOUS && (!M.grid_data || M.grid_res[0] < 1 || M.grid_res[1] < 1 || M.grid_res[2] < 1)) bad("heterogeneous medium without grid data");
         if (M.phase != LRT_PHASE_ISOTROPIC && M.phase != LRT_PHASE_HG) bad("invalid phase function");
         if (M.phase == LRT_PHASE_HG && !(M.g > -1.f && M.g < 1.f)) bad("The asymmetry parameter must lie in the interval (-1, 1)!");
     }
@@ -119,7 +120,7 @@ static void validate_desc(const lrt_scene_desc &d) {
     if (F.width <= 0 || F.height <= 0 || F.crop_width <= 0 || F.crop_height <= 0 || F.crop_offset_x < 0 || F.crop_offset_y < 0 ||
         F.crop_offset_x + F.crop_width > F.width || F.crop_offset_y + F.crop_height > F.height) bad("Invalid crop window specification!");
     if (F.rfilter < LRT_RFILTER_BOX || F.rfilter > LRT_RFILTER_TENT || (F.rfilter != LRT_RFILTER_BOX && !(F.rfilter_param > 0.f))) bad("invalid reconstruction filter");
-    if (d.integrator.type < LRT_INTEGRATOR_PATH || d.integrator.type > LRT_INTEGRATOR_BIOVOLPATH06) bad("invalid integrator type");
+    if (d.integrator.type < LRT_INTEGRATOR_PATH || d.integrator.type > LRT_INTEGRATOR_VOLPATHMIS) bad("invalid integrator type");
     if (d.integrator.max_depth < -1 || d.integrator.rr_depth <= 0) bad("invalid max_depth / rr_depth");
     if (d.sampler_type > LRT_SAMPLER_LD || d.sample_count == 0) bad("invalid sampler");
 }

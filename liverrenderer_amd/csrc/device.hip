@@ -53,6 +53,7 @@ struct DeviceScene {
     std::vector<hipEvent_t> ev_pool;
     std::vector<DMedium> h_media; DMedium *d_media = nullptr;
     std::vector<DBioMedium> h_bio; DBioMedium *d_bio = nullptr;
+    std::vector<DHetMedium> h_het; DHetMedium *d_het = nullptr; std::vector<float *> het_data; bool has_het = false, has_non_bio = false;
     DLdsInfo lds{}; bool use_lds = false; int n_cus = 256;
 
     template <typename T> T *track(T *p) { allocs.push_back((void *) p); return p; }
@@ -189,8 +190,18 @@ static void upload_media(DeviceScene *D, const lrt_scene_desc &d) {
         const lrt_medium_desc &M = d.media[i]; DMedium &o = D->h_media[i];
         for (int k = 0; k < 3; ++k) { o.sigma_t[k] = M.sigma_t[k] * M.scale; o.albedo[k] = M.albedo[k]; }   // homogeneous.cpp:121-126 eval_sigmat
         o.has_spectral_extinction = M.has_spectral_extinction; o.sample_emitters = M.sample_emitters; o.phase = M.phase; o.g = M.g;
-        o.scale = M.scale; o.pad = 0.f;
+        o.scale = M.scale; o.het = M.type == LRT_MEDIUM_HETEROGENEOUS ? 1 : 0;
     }
+    D->h_het.assign(std::max<uint32_t>(d.n_media, 1), DHetMedium{});
+    for (uint32_t i = 0; i < d.n_media; ++i) {
+        const lrt_medium_desc &M = d.media[i]; DHetMedium &o = D->h_het[i];
+        if (M.type != LRT_MEDIUM_HETEROGENEOUS) continue;
+        o.data = D->het_data[i];
+        for (int k = 0; k < 3; ++k) { o.res[k] = M.grid_res[k]; o.bbox_min[k] = M.grid_bbox_min[k]; o.bbox_max[k] = M.grid_bbox_max[k]; }
+        for (int k = 0; k < 12; ++k) o.to_local[k] = M.grid_to_local[k];
+        o.scale = M.scale; o.max_density = M.scale * M.grid_max;                    // heterogeneous.cpp:164,171
+    }
+    HIP_CHECK(hipMemcpyAsync(D->d_het, D->h_het.data(), D->h_het.size() * sizeof(DHetMedium), hipMemcpyHostToDevice, D->stream));
     HIP_CHECK(hipMemcpyAsync(D->d_media, D->h_media.data(), D->h_media.size() * sizeof(DMedium), hipMemcpyHostToDevice, D->stream));
 }
 
@@ -245,6 +256,7 @@ DeviceScene *device_scene_create(const lrt_scene_desc &d, int device) {
             LRT_SMEM((k_render<LRT_INTEGRATOR_PATH, 1024, true, true>)); LRT_SMEM((k_render<LRT_INTEGRATOR_VOLPATH, 1024, true, true>));
             LRT_SMEM((k_render<LRT_INTEGRATOR_BIOVOLPATH, 1024, true, false>)); LRT_SMEM((k_render<LRT_INTEGRATOR_BIOVOLPATH, 1024, true, true>));
             LRT_SMEM((k_render<LRT_INTEGRATOR_BIOVOLPATH06, 1024, true, false>)); LRT_SMEM((k_render<LRT_INTEGRATOR_BIOVOLPATH06, 1024, true, true>));
+            LRT_SMEM((k_render<LRT_INTEGRATOR_VOLPATH_HET, 1024, true, false>)); LRT_SMEM((k_render<LRT_INTEGRATOR_VOLPATH_HET, 1024, true, true>));
             LRT_SMEM((k_render_prb<false, 1024, true, false>)); LRT_SMEM((k_render_prb<true, 1024, true, false>));
             LRT_SMEM((k_render_prb<false, 1024, true, true>)); LRT_SMEM((k_render_prb<true, 1024, true, true>));
             LRT_SMEM((k_trace_lds<true>)); LRT_SMEM((k_trace_lds<false>));
@@ -320,7 +332,17 @@ DeviceScene *device_scene_create(const lrt_scene_desc &d, int device) {
     HIP_CHECK(hipMalloc((void **) &D->d_media, std::max<uint32_t>(d.n_media, 1) * sizeof(DMedium))); D->track(D->d_media);
     HIP_CHECK(hipMalloc((void **) &D->d_bio, std::max<uint32_t>(d.n_media, 1) * sizeof(DBioMedium))); D->track(D->d_bio);
     if (d.n_media > 64) throw std::runtime_error("at most 64 media are supported");
-    upload_media(D.get(), d); sc.media = D->d_media; sc.bio = D->d_bio;
+    HIP_CHECK(hipMalloc((void **) &D->d_het, std::max<uint32_t>(d.n_media, 1) * sizeof(DHetMedium))); D->track(D->d_het);
+    D->het_data.assign(std::max<uint32_t>(d.n_media, 1), nullptr);
+    for (uint32_t i = 0; i < d.n_media; ++i) {
+        const lrt_medium_desc &M = d.media[i];
+        if (M.type == LRT_MEDIUM_HOMOGENEOUS || M.type == LRT_MEDIUM_HETEROGENEOUS) D->has_non_bio = true;
+        if (M.type != LRT_MEDIUM_HETEROGENEOUS) continue;
+        if (!M.grid_data || M.grid_res[0] < 1 || M.grid_res[1] < 1 || M.grid_res[2] < 1 || !(M.grid_max > 0.f)) throw std::runtime_error("heterogeneous medium without a valid grid");
+        D->het_data[i] = D->track(dev_upload(M.grid_data, (size_t) M.grid_res[0] * M.grid_res[1] * M.grid_res[2], st));
+        D->has_het = true;
+    }
+    upload_media(D.get(), d); sc.media = D->d_media; sc.bio = D->d_bio; sc.het = D->d_het;
     // ---- bounds (src/render/scene.cpp:49; include/mitsuba/core/bbox.h:343-346; envmap.cpp:337-351)
     DEnv &E = sc.env; memset(&E, 0, sizeof(E)); E.type = -1; E.emitter = -1;
     {
@@ -375,7 +397,7 @@ DeviceScene *device_scene_create(const lrt_scene_desc &d, int device) {
             }
         }
     }
-    sc.nee_fast_reject = (d.n_emitters == 1 && !sc.has_null_bsdf && !getenv("LRT_NO_NEE_REJECT") &&
+    sc.nee_fast_reject = (d.n_emitters == 1 && !sc.has_null_bsdf && !D->has_het && !getenv("LRT_NO_NEE_REJECT") &&
                           (E.type == LRT_EMITTER_CONSTANT || (E.type == LRT_EMITTER_ENVMAP && env_interior_positive))) ? 1 : 0;
     sc.emitters = D->track(dev_upload(em.data(), em.size(), st));
     sc.env_data = (const float4 *) D->track(dev_upload(env_rgbx.data(), env_rgbx.size(), st));
@@ -400,7 +422,7 @@ void device_scene_update_params(DeviceScene *D, const lrt_scene_desc &d) {
 static void ensure_workspace(DeviceScene *D, uint32_t capacity) {
     if (D->capacity >= capacity) return;
     auto alloc_q = [&](DPathStreams &q) {
-        D->release(q.o_maxt); D->release(q.d_eta); D->release(q.tp_pdf); D->release(q.res_flags); D->release(q.lp_lane); D->release(q.rng); D->release(q.tdepth);
+        D->release(q.o_maxt); D->release(q.d_eta); D->release(q.tp_pdf); D->release(q.res_flags); D->release(q.lp_lane); D->release(q.rng); D->release(q.tdepth); D->release(q.hit); q.hit = nullptr;
         HIP_CHECK(hipMalloc((void **) &q.o_maxt, (size_t) capacity * 16)); D->track(q.o_maxt);
         HIP_CHECK(hipMalloc((void **) &q.d_eta, (size_t) capacity * 16)); D->track(q.d_eta);
         HIP_CHECK(hipMalloc((void **) &q.tp_pdf, (size_t) capacity * 16)); D->track(q.tp_pdf);
@@ -408,6 +430,7 @@ static void ensure_workspace(DeviceScene *D, uint32_t capacity) {
         HIP_CHECK(hipMalloc((void **) &q.lp_lane, (size_t) capacity * 16)); D->track(q.lp_lane);
         HIP_CHECK(hipMalloc((void **) &q.rng, (size_t) capacity * 8)); D->track(q.rng);
         HIP_CHECK(hipMalloc((void **) &q.tdepth, (size_t) capacity * 4)); D->track(q.tdepth);
+        if (D->has_het) { HIP_CHECK(hipMalloc((void **) &q.hit, (size_t) capacity * 16)); D->track(q.hit); }
     };
     HIP_CHECK(hipStreamSynchronize(D->stream));
     alloc_q(D->q[0]); alloc_q(D->q[1]);
@@ -555,6 +578,16 @@ static void launch_prb(DeviceScene *D, const DRenderParams &rp, const PoolGeomet
     HIP_CHECK(hipGetLastError());
 }
 
+// Which media an integrator can meet: the bio integrators call the 5-argument Medium::sample_interaction, which the base class
+// (homogeneous / heterogeneous media) answers with NotImplementedError (src/render/medium.cpp:83-90); the PRB adjoint here is
+// derived for homogeneous coefficients; volpathmis is not built.
+static void check_integrator_media(DeviceScene *D, int integrator) {
+    if ((integrator == LRT_INTEGRATOR_BIOVOLPATH || integrator == LRT_INTEGRATOR_BIOVOLPATH06) && D->has_non_bio)
+        throw std::runtime_error("NotImplementedError: sample_interaction (the bio integrators need liver / parenchyma / glissonCapsule media)");
+    if (integrator == LRT_INTEGRATOR_PRBVOLPATH && D->has_het) throw std::runtime_error("unsupported: prbvolpath with heterogeneous media");
+    if (integrator == LRT_INTEGRATOR_VOLPATHMIS) throw std::runtime_error("unsupported integrator: volpathmis is not implemented on the device yet");
+}
+
 // One persistent launch per render (k_render / k_render_prb): per-workgroup path pools, in-kernel regeneration; see
 // kernels.h.  sample_out != nullptr: per-lane test hook for lanes [lane_begin, lane_begin + n_lanes).
 static void run_wavefront(DeviceScene *D, const lrt_scene_desc &d, const ResolvedOpts &O, uint64_t lane_begin, uint64_t n_lanes,
@@ -564,6 +597,7 @@ static void run_wavefront(DeviceScene *D, const lrt_scene_desc &d, const Resolve
     rp.pixel_slot = pixel_list ? D->pixel_slot : nullptr;
     rp.pass_in = D->cur_pass_in; rp.pass_out = D->cur_pass_out;
     const bool prb = O.integrator == LRT_INTEGRATOR_PRBVOLPATH;
+    check_integrator_media(D, O.integrator);
     PoolGeometry g = pool_geometry(D, n_lanes);
     if (prb && D->use_lds) g.block = 1024;
     const uint32_t records = (uint32_t) std::min<uint64_t>((uint64_t) g.n_wg * 2u * g.P, 0xffffffffull);
@@ -588,7 +622,7 @@ static void run_wavefront(DeviceScene *D, const lrt_scene_desc &d, const Resolve
             case LRT_INTEGRATOR_PATH: LRT_LAUNCH(LRT_INTEGRATOR_PATH, BS, LDSB); break; \
             case LRT_INTEGRATOR_BIOVOLPATH: LRT_LAUNCH(LRT_INTEGRATOR_BIOVOLPATH, BS, LDSB); break; \
             case LRT_INTEGRATOR_BIOVOLPATH06: LRT_LAUNCH(LRT_INTEGRATOR_BIOVOLPATH06, BS, LDSB); break; \
-            default: LRT_LAUNCH(LRT_INTEGRATOR_VOLPATH, BS, LDSB); } } while (0)
+            default: if (D->has_het) LRT_LAUNCH(LRT_INTEGRATOR_VOLPATH_HET, BS, LDSB); else LRT_LAUNCH(LRT_INTEGRATOR_VOLPATH, BS, LDSB); } } while (0)
         if (D->use_lds) LRT_LAUNCH_I(1024, true); else LRT_LAUNCH_I(LRT_BLOCK, false);
         #undef LRT_LAUNCH_I
         #undef LRT_LAUNCH
@@ -737,6 +771,7 @@ void device_render_backward(DeviceScene *D, const lrt_scene_desc &d, const lrt_r
     lrt_render_opts oprb = opts ? *opts : lrt_render_opts{ -1, -2, -1, -1, 0, 0, 0, 1, 0, 0, 0, 0 };
     oprb.integrator = LRT_INTEGRATOR_PRBVOLPATH;                               // resolve as the adjoint integrator: RBIntegrator.render_backward has no pass split (common.py prepare())
     ResolvedOpts O = resolve(d, &oprb);
+    check_integrator_media(D, LRT_INTEGRATOR_PRBVOLPATH);
     const int grad_medium = opts ? opts->grad_medium : 0;
     if (grad_medium < -1 || grad_medium >= (int) d.n_media) throw std::runtime_error("lrt_render_backward: grad_medium " + std::to_string(grad_medium) + " is not a medium of the scene");
     hipStream_t st = D->stream;

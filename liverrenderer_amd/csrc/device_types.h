@@ -28,7 +28,7 @@ struct DTexture {
 struct DMedium {
     float sigma_t[3]; float albedo[3];   // sigma_t already multiplied by scale
     int32_t has_spectral_extinction, sample_emitters, phase; float g;
-    float scale; float pad;              // sigma_t = property * scale (needed by the PRB adjoint)
+    float scale; int32_t het;            // sigma_t = property * scale (needed by the PRB adjoint); het: heterogeneous (sc.het[index])
 };
 
 // bio media (liver / parenchyma / glissonCapsule): element coefficients of the 5-argument sample_interaction
@@ -41,6 +41,15 @@ struct DBioMedium {
     float hepatocity, log10_hep;              // log10_hep = log2(hepatocity + 1) / log2(10), filled by k_bio_prepare (device arithmetic)
     float sigmat[3];                          // what get_majorant reports: sigma_t * scale, or parenchyma's constants
     float pad;
+};
+
+// heterogeneous media (src/media/heterogeneous.cpp): sigma_t = scale * grid, majorant = scale * max(grid)
+struct DHetMedium {
+    const float *data;                        // x fastest
+    int32_t res[3]; float max_density;        // scale * grid_max (get_majorant)
+    float to_local[12];                       // world -> unit cube
+    float bbox_min[3], bbox_max[3];
+    float scale, pad;
 };
 
 struct DEmitter {
@@ -101,7 +110,7 @@ struct DScene {
     // geometry attributes
     const float *positions, *normals, *texcoords;
     const uint32_t *faces, *face_shape;
-    const DShape *shapes; const DBsdf *bsdfs; const DTexture *textures; const DMedium *media; const DBioMedium *bio; const DEmitter *emitters;
+    const DShape *shapes; const DBsdf *bsdfs; const DTexture *textures; const DMedium *media; const DBioMedium *bio; const DHetMedium *het; const DEmitter *emitters;
     const float *tex_data;
     const float4 *env_data;    // (w+1) x h RGBx
     const float *env_hier;
@@ -149,9 +158,13 @@ struct DPathStreams {
     float4 *lp_lane;           // last scatter position, lane id (bits)
     uint2  *rng;               // PCG32 state
     float  *tdepth;            // biovolpath / biovolpath06 only: the loop state `tissueDepth`
+    float4 *hit;               // volpath with heterogeneous media only: the surface interaction a null collision keeps (t, u, v, prim)
 };
 #define LRT_STATE_BYTES 88     // bytes per path record across all streams (path / volpath)
+#define LRT_STATE_BYTES_HET 104 // volpath with heterogeneous media: + the kept surface hit (float4)
 #define LRT_STATE_BYTES_BIO 92 // biovolpath*: + tissueDepth; the maxt slot carries the previous ray query's distance
+
+#define LRT_INTEGRATOR_VOLPATH_HET 101   // kernel selector (not an API value): volpath on a scene with heterogeneous media
 
 // flag word layout
 #define PF_DEPTH_MASK   0x0000ffffu
@@ -162,6 +175,7 @@ struct DPathStreams {
 #define PF_VALID        (1u << 27)
 #define PF_NOHIT        (1u << 28)     // look-ahead proved that the next free-flight segment reaches no surface
 #define PF_BIO_SCATTERED (1u << 29)    // biovolpath06: scattered_chain
+#define PF_HAVE_SI      (1u << 29)     // volpath, heterogeneous media: needs_intersection == false, the record's hit stream holds `si`
 #define PF_BIO_EMIT     (1u << 30)     // biovolpath06: type & 0x0001 (EmittedRadiance)
 #define PF_BIO_FULL     (1u << 31)     // biovolpath06: type & 0x0004 and type & 0x0008 (they only appear together)
 

@@ -683,6 +683,63 @@ DEV MI medium_sample_interaction(const DMedium &M, const Ray &ray, float sample,
     return mei;
 }
 
+// src/volumes/grid.cpp (one channel) through Dr.Jit's Texture3f::eval (trilinear, clamp): texel centres at (i + .5) / res,
+// lerp along x, then y, then z, each as fmadd(w0, a, w1 * b)
+DEV float grid_eval(const DHetMedium &H, V3 pl) {
+    const int rx = H.res[0], ry = H.res[1], rz = H.res[2];
+    float fx = fma_(pl.x, (float) rx, -.5f), fy = fma_(pl.y, (float) ry, -.5f), fz = fma_(pl.z, (float) rz, -.5f);
+    float flx = __builtin_floorf(fx), fly = __builtin_floorf(fy), flz = __builtin_floorf(fz);
+    float w1x = fx - flx, w1y = fy - fly, w1z = fz - flz, w0x = 1.f - w1x, w0y = 1.f - w1y, w0z = 1.f - w1z;
+    auto cl = [](float v, int n) { int i = (v < -2e9f) ? -2000000000 : (v > 2e9f ? 2000000000 : (int) v); return i < 0 ? 0 : (i > n - 1 ? n - 1 : i); };
+    int x0 = cl(flx, rx), x1 = cl(flx + 1.f, rx), y0 = cl(fly, ry), y1 = cl(fly + 1.f, ry), z0 = cl(flz, rz), z1 = cl(flz + 1.f, rz);
+    const float *d = H.data;
+    auto at = [&](int x, int y, int z) { return d[((size_t) z * ry + y) * rx + x]; };
+    float c00 = fma_(w0x, at(x0, y0, z0), w1x * at(x1, y0, z0)), c10 = fma_(w0x, at(x0, y1, z0), w1x * at(x1, y1, z0));
+    float c01 = fma_(w0x, at(x0, y0, z1), w1x * at(x1, y0, z1)), c11 = fma_(w0x, at(x0, y1, z1), w1x * at(x1, y1, z1));
+    float c0 = fma_(w0y, c00, w1y * c10), c1 = fma_(w0y, c01, w1y * c11);
+    return fma_(w0z, c0, w1z * c1);
+}
+
+// include/mitsuba/core/bbox.h:303-340 (Williams et al.)
+DEV bool bbox_ray_intersect(const float *lo, const float *hi, const Ray &ray, float &mint, float &maxt) {
+    bool active = ray.d.x != 0.f || ray.d.y != 0.f || ray.d.z != 0.f;
+    const float dx = rcp(ray.d.x), dy = rcp(ray.d.y), dz = rcp(ray.d.z);
+    float t0x = ((dx >= 0.f ? lo[0] : hi[0]) - ray.o.x) * dx, t1x = ((dx >= 0.f ? hi[0] : lo[0]) - ray.o.x) * dx;
+    float t0y = ((dy >= 0.f ? lo[1] : hi[1]) - ray.o.y) * dy, t1y = ((dy >= 0.f ? hi[1] : lo[1]) - ray.o.y) * dy;
+    float t0z = ((dz >= 0.f ? lo[2] : hi[2]) - ray.o.z) * dz, t1z = ((dz >= 0.f ? hi[2] : lo[2]) - ray.o.z) * dz;
+    auto max_safe = [](float a, float b) { return (a > b || !finite_(b)) ? a : b; };
+    auto min_safe = [](float a, float b) { return (a < b || !finite_(b)) ? a : b; };
+    active = active && !((t0x > t1y) || (t0y > t1x));
+    t0x = max_safe(t0x, t0y); t1x = min_safe(t1x, t1y);
+    active = active && !((t0x > t1z) || (t0z > t1x));
+    t0x = max_safe(t0x, t0z); t1x = min_safe(t1x, t1z);
+    mint = t0x; maxt = t1x;
+    return active;
+}
+
+// src/render/medium.cpp:40-82 + src/media/heterogeneous.cpp:178-200: delta-tracking majorant, sigma_n = majorant - sigma_t(p)
+DEV MI het_sample_interaction(const DMedium &M, const DHetMedium &H, const Ray &ray, float sample) {
+    MI mei; mei.wi = -ray.d;
+    float mint, maxt;
+    bool active = bbox_ray_intersect(H.bbox_min, H.bbox_max, ray, mint, maxt);
+    active = active && (finite_(mint) || finite_(maxt));
+    if (!active) { mint = 0.f; maxt = kInf; }
+    mint = fmax_(0.f, mint); maxt = fmin_(ray.maxt, maxt);
+    const float max_density = H.max_density;
+    float sampled_t = mint + (-m_log(1.f - sample) / max_density);
+    bool valid = active && sampled_t <= maxt;
+    mei.t = valid ? sampled_t : kInf;
+    mei.p = fma3(ray.d, sampled_t, ray.o);
+    mei.mint = mint;
+    float st = 0.f;
+    if (valid) st = H.scale * grid_eval(H, xform_point12(H.to_local, mei.p));
+    V3 albedo(M.albedo[0], M.albedo[1], M.albedo[2]);
+    mei.sigma_t = V3(st); mei.sigma_s = mei.sigma_t * (valid ? albedo : V3(0.f));
+    mei.sigma_n = V3(max_density) - mei.sigma_t;
+    mei.combined = V3(max_density);
+    return mei;
+}
+
 // src/phase/hg.cpp:64-99, src/phase/isotropic.cpp:39-58
 DEV float hg_eval(float g, float cos_theta) {
     float temp = 1.f + sqr(g) + 2.f * g * cos_theta;

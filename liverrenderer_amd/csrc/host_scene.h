@@ -20,6 +20,7 @@ struct SceneStorage {
     std::vector<lrt_medium_desc> media;
     std::vector<lrt_emitter_desc> emitters;
     std::vector<std::vector<float>> emdata;
+    std::vector<std::vector<float>> meddata;   // heterogeneous media: grid values
     lrt_scene_desc desc{};
     void fix_pointers();                 // re-point desc at the vectors above
     void copy_from(const lrt_scene_desc &d);

@@ -18,27 +18,31 @@ namespace lrt {
 struct PathState {
     V3 o, d, tp, res, lp; float maxt, eta, last_pdf; uint32_t flags, lane; uint64_t rng_state;
     float tdepth, si_t;        // biovolpath / biovolpath06: `tissueDepth`, distance returned by the previous trip's ray query
+    float4 hit;                // volpath, heterogeneous media: the surface hit (t, u, v, prim) a null collision keeps (PF_HAVE_SI)
 };
 
 // BIO: a queued path's ray always comes from spawn_ray (maxt = largest float), so its maxt slot carries si_t instead, and
 // the seventh stream holds tissueDepth (92 B records)
-template <bool BIO = false, typename QS>
+// MODE: 0 path / volpath (88 B), 1 biovolpath* (92 B), 2 volpath with heterogeneous media (104 B)
+template <int MODE = 0, typename QS>
 DEV void load_state(const QS &q, size_t i, PathState &s) {
     float4 a = q.o_maxt[i], b = q.d_eta[i], c = q.tp_pdf[i], d = q.res_flags[i], e = q.lp_lane[i]; uint2 r = q.rng[i];
     s.o = V3(a.x, a.y, a.z); s.maxt = a.w; s.d = V3(b.x, b.y, b.z); s.eta = b.w;
     s.tp = V3(c.x, c.y, c.z); s.last_pdf = c.w; s.res = V3(d.x, d.y, d.z); s.flags = f2u(d.w);
     s.lp = V3(e.x, e.y, e.z); s.lane = f2u(e.w); s.rng_state = ((uint64_t) r.y << 32) | r.x;
-    if (BIO) { s.si_t = a.w; s.maxt = kLargest; s.tdepth = q.tdepth[i]; }
+    if (MODE == 1) { s.si_t = a.w; s.maxt = kLargest; s.tdepth = q.tdepth[i]; }
+    if (MODE == 2) s.hit = q.hit[i];
 }
-template <bool BIO = false, typename QS>
+template <int MODE = 0, typename QS>
 DEV void store_state(const QS &q, size_t i, const PathState &s) {
-    q.o_maxt[i] = make_float4(s.o.x, s.o.y, s.o.z, BIO ? s.si_t : s.maxt);
+    q.o_maxt[i] = make_float4(s.o.x, s.o.y, s.o.z, MODE == 1 ? s.si_t : s.maxt);
     q.d_eta[i] = make_float4(s.d.x, s.d.y, s.d.z, s.eta);
     q.tp_pdf[i] = make_float4(s.tp.x, s.tp.y, s.tp.z, s.last_pdf);
     q.res_flags[i] = make_float4(s.res.x, s.res.y, s.res.z, u2f(s.flags));
     q.lp_lane[i] = make_float4(s.lp.x, s.lp.y, s.lp.z, u2f(s.lane));
     q.rng[i] = make_uint2((uint32_t) s.rng_state, (uint32_t) (s.rng_state >> 32));
-    if (BIO) q.tdepth[i] = s.tdepth;
+    if (MODE == 1) q.tdepth[i] = s.tdepth;
+    if (MODE == 2) q.hit[i] = s.hit;
 }
 
 // Sampler::seed in the JIT branch of SamplingIntegrator::render (integrator.cpp:308-311): independent: TEA4(base + seed,
@@ -126,7 +130,7 @@ DEV PathState generate_camera_path(SceneRef sc, RpRef rp, const uint32_t *__rest
     Ray ray = camera_ray(sc, fma_(spx, sc.film.scale_x, sc.film.offset_x), fma_(spy, sc.film.scale_y, sc.film.offset_y));
     PathState s;
     s.o = ray.o; s.d = ray.d; s.maxt = ray.maxt; s.eta = 1.f; s.tp = V3(1.f); s.res = V3(0.f); s.lp = V3(0.f); s.last_pdf = 1.f; s.lane = lane;
-    s.tdepth = 0.f; s.si_t = kInf;                                                   // biovolpath.cpp:125,129: si = zeros (t = inf), tissueDepth = 0
+    s.tdepth = 0.f; s.si_t = kInf; s.hit = make_float4(0.f, 0.f, 0.f, 0.f);                                                   // biovolpath.cpp:125,129: si = zeros (t = inf), tissueDepth = 0
     bool env_visible = !rp.hide_emitters && sc.env.type >= 0;
     uint32_t flags = env_visible ? PF_VALID : 0u;
     if (rp.integrator == LRT_INTEGRATOR_PATH) flags |= PF_SPECULAR;                 // prev_bsdf_delta = true
@@ -250,7 +254,7 @@ DEV void finish_paths_wave(SceneRef sc, RpRef rp, float *__restrict__ film, floa
 
 // ---------------------------------------------------------- volpath NEE
 // src/integrators/volpath.cpp:400-554.  ref_n is zero for medium interactions.
-template <typename SMP, typename TR>
+template <bool HET, typename SMP, typename TR>
 DEV V3 volpath_sample_emitter(SceneRef sc, SMP &rng, V3 ref_p, V3 ref_n, bool ref_is_surface, uint32_t ref_shape, V3 ref_geo_n,
                               int medium, uint32_t channel, DirSample *ds_out, const TR &tr, uint32_t &n_shadow) {
     V3 transmittance(1.f);
@@ -272,12 +276,13 @@ DEV V3 volpath_sample_emitter(SceneRef sc, SMP &rng, V3 ref_p, V3 ref_n, bool re
         if (!active_medium) rng.skip(1);                                // volpath.cpp:479
         if (active_medium) {
             const DMedium M = sc.media[medium];
-            MI mei = medium_sample_interaction(M, ray, rng.next(), channel);
-            if (mei.valid()) ray.maxt = fmin_(mei.t, remaining_dist);
+            const bool het = HET && M.het;
+            MI mei = het ? het_sample_interaction(M, sc.het[medium], ray, rng.next()) : medium_sample_interaction(M, ray, rng.next(), channel);
+            if (mei.valid() && !het) ray.maxt = fmin_(mei.t, remaining_dist);    // medium->is_homogeneous() only (volpath.cpp:481)
             if (needs_intersection) {
                 // Exact shortcut: a real collision (sigma_n = 0) kills the sample whether or not a
                 // surface lies in front of it when every surface blocks (no null BSDF): skip the query.
-                bool elide = mei.valid() && !sc.has_null_bsdf;
+                bool elide = mei.valid() && !sc.has_null_bsdf && !het;
                 if (!elide) { n_shadow++; Hit h = tr.closest(ray); si = compute_si(sc, ray, h); }
                 else { si.valid = false; si.t = kInf; }
             }
@@ -322,10 +327,15 @@ DEV V3 volpath_sample_emitter(SceneRef sc, SMP &rng, V3 ref_p, V3 ref_n, bool re
 
 // One trip of volpath's while_loop (src/integrators/volpath.cpp:170-391).
 // Returns true when the path survives.
-template <typename SMP, typename TR>
+// HET: the scene holds heterogeneous media (delta tracking, volpath.cpp:238-259): a null collision moves the ray origin
+// and keeps the surface interaction found earlier (`needs_intersection` stays false), which the record carries as a hit.
+template <bool HET, typename SMP, typename TR>
 DEV bool volpath_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, const TR &tr, uint32_t &n_shadow, uint32_t &n_extra) {
     uint32_t depth = s.flags & PF_DEPTH_MASK;
     const bool proven_empty = (s.flags & PF_NOHIT) != 0;
+    const bool needs_intersection = !(HET && (s.flags & PF_HAVE_SI));
+    bool act_null_scatter = false;
+    Hit hkeep; hkeep.t = s.hit.x; hkeep.u = s.hit.y; hkeep.v = s.hit.z; hkeep.prim = f2u(s.hit.w);
     int medium = (int) ((s.flags & PF_MEDIUM_MASK) >> PF_MEDIUM_SHIFT) - 1;
     const uint32_t channel = (s.flags >> PF_CHANNEL_SHIFT) & 3u;
     bool specular_chain = (s.flags & PF_SPECULAR) != 0, valid_ray = (s.flags & PF_VALID) != 0;
@@ -354,9 +364,11 @@ DEV bool volpath_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, const 
     if (!active_medium) rng.skip(2);                                    // volpath.cpp:220,239
     if (active_medium) {
         const DMedium M = sc.media[medium];
-        mei = medium_sample_interaction(M, ray, rng.next(), channel);
-        if (mei.valid()) ray.maxt = mei.t;
-        if (!proven_empty) { Hit h = tr.closest(ray); si = compute_si(sc, ray, h); }   // else: no surface within mei.t (look-ahead of the previous trip)
+        const bool het = HET && M.het;
+        mei = het ? het_sample_interaction(M, sc.het[medium], ray, rng.next()) : medium_sample_interaction(M, ray, rng.next(), channel);
+        if (mei.valid() && !het) ray.maxt = mei.t;                              // medium->is_homogeneous() only (volpath.cpp:221)
+        if (!needs_intersection) si = compute_si(sc, ray, hkeep);                // the interaction a null collision kept
+        else if (!proven_empty) { hkeep = tr.closest(ray); si = compute_si(sc, ray, hkeep); }   // else: no surface within mei.t (look-ahead of the previous trip)
 #ifdef LRT_EXPERIMENT
         if (!proven_empty && (rp.profile & 0x10000u)) { Ray r2 = ray; r2.o.x += 1e-30f; Hit h = tr.closest(r2); if (h.t == -1.f) si.t = 0.f; }
         if (!proven_empty && (rp.profile & 0x20000u)) { Ray r2 = ray; r2.o.x += 1e-30f; Hit h; h.prim = si.valid ? si.prim : 0xffffffffu; h.t = si.t; h.u = si.uv.x; h.v = si.uv.y; SI s2 = compute_si(sc, r2, h); if (s2.t == -1.f) si.t = 0.f; }
@@ -373,14 +385,19 @@ DEV bool volpath_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, const 
         active_medium = mei.valid();
         if (!active_medium) rng.skip(1);              // volpath.cpp:239
         if (active_medium) {
-            (void) rng.next();                        // null/real collision draw (sigma_n = 0: always real)
-            act_medium_scatter = true;
-            depth += 1;
-            s.lp = mei.p;
+            const float u_null = rng.next();          // null/real collision draw (sigma_n = 0: always real)
+            if (HET) {                                // volpath.cpp:238-250
+                const float null_scatter_prob = mean3(mei.sigma_n / mei.combined);
+                act_null_scatter = u_null < null_scatter_prob;
+                if (M.has_spectral_extinction && act_null_scatter) throughput = throughput * (mei.sigma_n / null_scatter_prob);
+            }
+            act_medium_scatter = !act_null_scatter;
+            if (act_medium_scatter) { depth += 1; s.lp = mei.p; }
         }
     }
     active = active && depth < max_depth;
     act_medium_scatter = act_medium_scatter && active;
+    if (HET && act_null_scatter) { ray.o = mei.p; hkeep.t = si.t - mei.t; }    // :254-257 (si.t -= mei.t)
     if (!act_medium_scatter) rng.skip(3);                               // volpath.cpp:407 (NEE), 288, 289
     if (act_medium_scatter) {
         const DMedium M = sc.media[medium];
@@ -413,7 +430,7 @@ DEV bool volpath_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, const 
             }
             if (!rejected) {
                 DirSample ds;
-                V3 emitted = volpath_sample_emitter(sc, rng, mei.p, V3(0.f), false, 0, V3(0.f), medium, channel, &ds, tr, n_shadow);
+                V3 emitted = volpath_sample_emitter<HET>(sc, rng, mei.p, V3(0.f), false, 0, V3(0.f), medium, channel, &ds, tr, n_shadow);
                 float phase_val = phase_eval(M, mei.wi, ds.d);
                 V3 c = throughput * phase_val * emitted * mis_weight(ds.pdf, ds.delta ? 0.f : phase_val);
                 result = result + c;
@@ -466,7 +483,7 @@ DEV bool volpath_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, const 
         if (!active_e) rng.skip(1);
         if (active_e) {
             DirSample ds;
-            V3 emitted = volpath_sample_emitter(sc, rng, si.p, si.n, true, si.shape, si.n, medium, channel, &ds, tr, n_shadow);
+            V3 emitted = volpath_sample_emitter<HET>(sc, rng, si.p, si.n, true, si.shape, si.n, medium, channel, &ds, tr, n_shadow);
             V3 wo = si.sh.to_local(ds.d);
             V3 bsdf_val = bsdf_eval(sc, b, si, wo);
             float bpdf = bsdf_pdf(sc, b, si, wo);
@@ -506,14 +523,17 @@ DEV bool volpath_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, const 
         if (a2) { float u = pk.next(); a2 = (u < q2) || !(depth > (uint32_t) rp.rr_depth); }
         a2 = a2 && depth < max_depth;
         if (!a2) { active = false; n_extra += 1; rng = pk; }      // the retired trip's Russian-roulette draw stays consumed (multi-pass renders)
-        else if (medium >= 0 && sc.grid.enabled) {
+        else if (medium >= 0 && sc.grid.enabled && !(HET && act_null_scatter)) {
             const DMedium M = sc.media[medium];
-            MI m2 = medium_sample_interaction(M, ray, pk.next(), channel);
-            if (m2.valid() && segment_proven_empty(sc.grid, ray.o, ray.d, m2.t)) nohit = PF_NOHIT;
+            if (!(HET && M.het)) {                    // a heterogeneous medium does not shorten the ray: its query is always the full one
+                MI m2 = medium_sample_interaction(M, ray, pk.next(), channel);
+                if (m2.valid() && segment_proven_empty(sc.grid, ray.o, ray.d, m2.t)) nohit = PF_NOHIT;
+            }
         }
     }
     commit();
     s.flags |= nohit;
+    if (HET && act_null_scatter && active) { s.flags |= PF_HAVE_SI; s.hit = make_float4(hkeep.t, hkeep.u, hkeep.v, u2f(hkeep.prim)); }
     return active;
 }
 
@@ -629,11 +649,11 @@ namespace lrt {
 // n_a + n_b + n_c <= P, so the regions never collide.  No cross-workgroup dependency exists besides the lane ticket and the
 // film atomics; every wave leaves its loops once the ticket is exhausted and its pool is empty.
 template <typename QS> DEV DPathStreams offset_streams(const QS &q, size_t off) {
-    DPathStreams r; r.o_maxt = q.o_maxt + off; r.d_eta = q.d_eta + off; r.tp_pdf = q.tp_pdf + off; r.res_flags = q.res_flags + off; r.lp_lane = q.lp_lane + off; r.rng = q.rng + off; r.tdepth = q.tdepth + off;
+    DPathStreams r; r.o_maxt = q.o_maxt + off; r.d_eta = q.d_eta + off; r.tp_pdf = q.tp_pdf + off; r.res_flags = q.res_flags + off; r.lp_lane = q.lp_lane + off; r.rng = q.rng + off; r.tdepth = q.tdepth + off; r.hit = q.hit + off;
     return r;
 }
 
-template <bool BIO = false>
+template <int MODE = 0>
 DEV void retire_and_compact_wave(SceneRef sc, RpRef rp, bool had_path, bool alive, const PathState &s,
                                  float *__restrict__ film, float *__restrict__ sample_out, uint64_t sample_base,
                                  const LRT_CONST DPathStreams &qout, size_t pool, uint32_t P, uint32_t *s_out /* LDS [3] */) {
@@ -651,7 +671,7 @@ DEV void retire_and_compact_wave(SceneRef sc, RpRef rp, bool had_path, bool aliv
     if (alive) {
         const unsigned long long mine = region == 0 ? m0 : (region == 1 ? m1 : m2);
         const uint32_t slot = b + (uint32_t) __popcll(mine & ((1ull << lane_in_wave) - 1ull));
-        store_state<BIO>(qout, pool + (region == 0 ? slot : (region == 1 ? P + slot : 2u * P - 1u - slot)), s);
+        store_state<MODE>(qout, pool + (region == 0 ? slot : (region == 1 ? P + slot : 2u * P - 1u - slot)), s);
     }
 }
 
@@ -668,7 +688,7 @@ k_render(ScenePtr scp, LaunchPtr lp) {
     __shared__ uint32_t s_in[3], s_out[3], s_ticket, s_fresh;
     __shared__ unsigned long long s_fresh_base, s_prof[8];
     const uint32_t tid = threadIdx.x, lane_in_wave = tid & 63u;
-    constexpr bool BIO = INTEGRATOR == LRT_INTEGRATOR_BIOVOLPATH || INTEGRATOR == LRT_INTEGRATOR_BIOVOLPATH06;
+    constexpr int MODE = (INTEGRATOR == LRT_INTEGRATOR_BIOVOLPATH || INTEGRATOR == LRT_INTEGRATOR_BIOVOLPATH06) ? 1 : (INTEGRATOR == LRT_INTEGRATOR_VOLPATH_HET ? 2 : 0);
     if (tid < 8) s_prof[tid] = 0;
     LdsScene L{};
     if (LDS_BVH) {
@@ -715,7 +735,7 @@ k_render(ScenePtr scp, LaunchPtr lp) {
                 if (t < ta) { i = (t << 6) + lane_in_wave; had_path = i < n_a; }
                 else if (t < ta + tc) { i = ((t - ta) << 6) + lane_in_wave; had_path = i < n_c; i += P; }
                 else { i = ((t - ta - tc) << 6) + lane_in_wave; had_path = i < n_b; i = 2u * P - 1u - i; }
-                if (had_path) { load_state<BIO>(parity ? A.q1 : A.q0, pool + i, s); n_loaded += 1; }
+                if (had_path) { load_state<MODE>(parity ? A.q1 : A.q0, pool + i, s); n_loaded += 1; }
             } else {
                 const uint32_t i = ((t - ta - tc - tb) << 6) + lane_in_wave;
                 had_path = i < fresh;
@@ -737,7 +757,8 @@ k_render(ScenePtr scp, LaunchPtr lp) {
                 if (INTEGRATOR == LRT_INTEGRATOR_PATH) alive = LDS_BVH ? path_iteration(sc, rp, s, rng, tr_lds, n_shadow) : path_iteration(sc, rp, s, rng, tr_glb, n_shadow);
                 else if (INTEGRATOR == LRT_INTEGRATOR_BIOVOLPATH) alive = LDS_BVH ? biovolpath_iteration(sc, rp, s, rng, tr_lds, n_shadow, n_extra) : biovolpath_iteration(sc, rp, s, rng, tr_glb, n_shadow, n_extra);
                 else if (INTEGRATOR == LRT_INTEGRATOR_BIOVOLPATH06) alive = LDS_BVH ? biovolpath06_iteration(sc, rp, s, rng, tr_lds) : biovolpath06_iteration(sc, rp, s, rng, tr_glb);
-                else alive = LDS_BVH ? volpath_iteration(sc, rp, s, rng, tr_lds, n_shadow, n_extra) : volpath_iteration(sc, rp, s, rng, tr_glb, n_shadow, n_extra);
+                else if (INTEGRATOR == LRT_INTEGRATOR_VOLPATH_HET) alive = LDS_BVH ? volpath_iteration<true>(sc, rp, s, rng, tr_lds, n_shadow, n_extra) : volpath_iteration<true>(sc, rp, s, rng, tr_glb, n_shadow, n_extra);
+                else alive = LDS_BVH ? volpath_iteration<false>(sc, rp, s, rng, tr_lds, n_shadow, n_extra) : volpath_iteration<false>(sc, rp, s, rng, tr_glb, n_shadow, n_extra);
                 s.rng_state = rng.state;
                 n_trips += 1;
             }
@@ -750,13 +771,13 @@ k_render(ScenePtr scp, LaunchPtr lp) {
                     if (had_path) {
                         SamplerT<LD> rng = lane_rng_resume<LD>(rp, s2.lane, s2.rng_state);
                         if (INTEGRATOR == LRT_INTEGRATOR_PATH) alive2 = LDS_BVH ? path_iteration(sc, rp, s2, rng, tr_lds, d0) : path_iteration(sc, rp, s2, rng, tr_glb, d0);
-                        else alive2 = LDS_BVH ? volpath_iteration(sc, rp, s2, rng, tr_lds, d0, d1) : volpath_iteration(sc, rp, s2, rng, tr_glb, d0, d1);
+                        else alive2 = LDS_BVH ? volpath_iteration<false>(sc, rp, s2, rng, tr_lds, d0, d1) : volpath_iteration<false>(sc, rp, s2, rng, tr_glb, d0, d1);
                     }
                     if (alive2 && s2.flags == 0xdeadbeefu) s.res.x += s2.res.x;
                 }
             }
 #endif
-            retire_and_compact_wave<BIO>(sc, rp, had_path, alive, s, A.film, A.sample_out, A.sample_base, parity ? A.q0 : A.q1, pool, P, s_out);
+            retire_and_compact_wave<MODE>(sc, rp, had_path, alive, s, A.film, A.sample_out, A.sample_base, parity ? A.q0 : A.q1, pool, P, s_out);
             if ((rp.profile & 1u) && lane_in_wave == 0) {
                 const int region = t < ta ? 0 : (t < ta + tc ? 1 : (t < ta + tc + tb ? 2 : 3));
                 atomicAdd(&s_prof[region], wall_clock64() - t_begin); atomicAdd(&s_prof[4 + region], 1ull);

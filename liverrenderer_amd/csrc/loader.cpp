@@ -26,7 +26,8 @@ void SceneStorage::fix_pointers() {
     desc.n_vertices = (uint32_t) (positions.size() / 3); desc.n_faces = (uint32_t) (faces.size() / 3);
     desc.n_shapes = (uint32_t) shapes.size(); desc.n_bsdfs = (uint32_t) bsdfs.size(); desc.n_textures = (uint32_t) textures.size();
     desc.n_media = (uint32_t) media.size(); desc.n_emitters = (uint32_t) emitters.size();
-    texdata.resize(textures.size()); emdata.resize(emitters.size());
+    texdata.resize(textures.size()); emdata.resize(emitters.size()); meddata.resize(media.size());
+    for (size_t i = 0; i < media.size(); ++i) media[i].grid_data = meddata[i].empty() ? nullptr : meddata[i].data();
     for (size_t i = 0; i < textures.size(); ++i) textures[i].data = texdata[i].empty() ? nullptr : texdata[i].data();
     for (size_t i = 0; i < emitters.size(); ++i) emitters[i].data = emdata[i].empty() ? nullptr : emdata[i].data();
     desc.positions = positions.data(); desc.normals = normals.data(); desc.texcoords = texcoords.data();
@@ -46,7 +47,10 @@ void SceneStorage::copy_from(const lrt_scene_desc &d) {
     textures.assign(d.textures, d.textures + d.n_textures);
     media.assign(d.media, d.media + d.n_media);
     emitters.assign(d.emitters, d.emitters + d.n_emitters);
-    texdata.assign(textures.size(), {}); emdata.assign(emitters.size(), {});
+    texdata.assign(textures.size(), {}); emdata.assign(emitters.size(), {}); meddata.assign(media.size(), {});
+    for (size_t i = 0; i < media.size(); ++i)
+        if (media[i].type == LRT_MEDIUM_HETEROGENEOUS && media[i].grid_data)
+            meddata[i].assign(media[i].grid_data, media[i].grid_data + (size_t) media[i].grid_res[0] * media[i].grid_res[1] * media[i].grid_res[2]);
     for (size_t i = 0; i < textures.size(); ++i)
         if (textures[i].type == LRT_TEX_BITMAP && textures[i].data)
             texdata[i].assign(textures[i].data, textures[i].data + (size_t) textures[i].width * textures[i].height * textures[i].channels);
@@ -350,10 +354,19 @@ struct Loader {
         else if (o->type == "liver") M.type = LRT_MEDIUM_LIVER;
         else if (o->type == "parenchyma") M.type = LRT_MEDIUM_PARENCHYMA;
         else if (o->type == "glissonCapsule") M.type = LRT_MEDIUM_GLISSON;
+        else if (o->type == "heterogeneous") M.type = LRT_MEDIUM_HETEROGENEOUS;
         else fail("unsupported medium type \"" + o->type + "\"");
+        std::vector<float> grid;
         const bool parenchyma = M.type == LRT_MEDIUM_PARENCHYMA;
         // src/media/homogeneous.cpp:112-119, src/media/liver.cpp:139-141,193-194, src/media/parenchyma.cpp:140-151
-        get_rgb(*o, "sigma_t", 1.f, M.sigma_t); get_rgb(*o, "albedo", .75f, M.albedo);
+        if (M.type == LRT_MEDIUM_HETEROGENEOUS) {                                 // src/media/heterogeneous.cpp:156-164
+            ObjP vol = child(*o, "volume", "sigma_t");
+            if (!vol) fail("heterogeneous medium: `sigma_t` must be a gridvolume (constant volumes: use a homogeneous medium)");
+            load_grid_volume(*vol, M, grid);
+            for (auto &c : o->children) if (c.second->tag == "volume" && c.first == "albedo") fail("unsupported: a volume as the albedo of a heterogeneous medium");
+            M.sigma_t[0] = M.sigma_t[1] = M.sigma_t[2] = 1.f;
+            get_rgb(*o, "albedo", .75f, M.albedo);
+        } else { get_rgb(*o, "sigma_t", 1.f, M.sigma_t); get_rgb(*o, "albedo", .75f, M.albedo); }
         M.scale = get_float(*o, "scale", 1.f);
         M.has_spectral_extinction = get_bool(*o, "has_spectral_extinction", !parenchyma);
         M.sample_emitters = get_bool(*o, "sample_emitters", !parenchyma);
@@ -388,7 +401,45 @@ struct Loader {
             M.sigma_hepatocity = get_float(*o, "sigma_hepatocity", 1.f);
         }
         snprintf(M.id, sizeof(M.id), "%s", o->id.empty() ? ("medium" + std::to_string(S.media.size())).c_str() : o->id.c_str());
-        S.media.push_back(M); int ix = (int) S.media.size() - 1; medium_ix[o.get()] = ix; return ix;
+        S.media.push_back(M); S.meddata.resize(S.media.size()); S.meddata.back() = std::move(grid);
+        int ix = (int) S.media.size() - 1; medium_ix[o.get()] = ix; return ix;
+    }
+
+    // src/volumes/grid.cpp:159-330 (one channel, trilinear, clamp) + src/render/volumegrid.cpp:29-83 (the .vol file)
+    void load_grid_volume(const Obj &v, lrt_medium_desc &M, std::vector<float> &grid) {
+        if (v.type != "gridvolume") fail("unsupported volume type \"" + v.type + "\" (supported: gridvolume)");
+        if (get_string(v, "filter_type", "trilinear") != "trilinear" || get_string(v, "wrap_mode", "clamp") != "clamp") fail("gridvolume: only trilinear / clamp is supported");
+        if (has(v, "max_value")) fail("gridvolume: max_value is not supported");
+        std::string path = resolve(get_string(v, "filename", nullptr));
+        FILE *f = fopen(path.c_str(), "rb"); if (!f) fail("cannot open \"" + path + "\"");
+        unsigned char hdr[4]; int32_t meta[5]; float dims[6];
+        bool ok = fread(hdr, 1, 4, f) == 4 && fread(meta, 4, 5, f) == 5 && fread(dims, 4, 6, f) == 6;
+        if (!ok || hdr[0] != 'V' || hdr[1] != 'O' || hdr[2] != 'L') { fclose(f); fail("Invalid volume file!"); }
+        if (hdr[3] != 3 || meta[0] != 1) { fclose(f); fail("volume file: only version 3 / Float32 data is supported"); }
+        if (meta[4] != 1) { fclose(f); fail("unsupported: grid volumes with more than one channel"); }
+        if (meta[1] < 1 || meta[2] < 1 || meta[3] < 1 || (int64_t) meta[1] * meta[2] * meta[3] > (1ll << 28)) { fclose(f); fail("volume file: invalid dimensions"); }
+        const size_t n = (size_t) meta[1] * meta[2] * meta[3];
+        grid.resize(n);
+        ok = fread(grid.data(), 4, n, f) == n; fclose(f);
+        if (!ok) fail("volume file: truncated data");
+        M.grid_res[0] = meta[1]; M.grid_res[1] = meta[2]; M.grid_res[2] = meta[3];
+        float mx = -INFINITY; for (float x : grid) mx = std::max(mx, x);
+        M.grid_max = mx;
+        // m_to_local = to_world^-1 (Volume base class); use_grid_bbox: the file's bounding box maps onto the unit cube first
+        Mat4 TW = get_xform(v, "to_world"), TL = inverse_affine(TW);
+        if (get_bool(v, "use_grid_bbox", false)) {                                // VolumeGrid::bbox_transform: scale(1 / extents) * translate(-min)
+            Mat4 B = ident();
+            for (int a = 0; a < 3; ++a) { double e = (double) dims[3 + a] - (double) dims[a]; B.m[5 * a] = 1.0 / e; B.m[4 * a + 3] = -(double) dims[a] / e; }
+            TL = mul(B, TL);
+        }
+        float tl[16]; to_float(TL, tl); memcpy(M.grid_to_local, tl, sizeof(float) * 12);
+        Mat4 TWL = inverse_affine(TL); float tw[16]; to_float(TWL, tw);           // update_bbox(): world-space bounds of the unit cube
+        for (int a = 0; a < 3; ++a) { M.grid_bbox_min[a] = INFINITY; M.grid_bbox_max[a] = -INFINITY; }
+        for (int c = 0; c < 8; ++c) {
+            F3 p = xf_point(tw, { (float) (c >> 2 & 1), (float) (c >> 1 & 1), (float) (c & 1) });
+            const float q[3] = { p.x, p.y, p.z };
+            for (int a = 0; a < 3; ++a) { M.grid_bbox_min[a] = std::min(M.grid_bbox_min[a], q[a]); M.grid_bbox_max[a] = std::max(M.grid_bbox_max[a], q[a]); }
+        }
     }
 
     uint32_t add_vertex(F3 p, F3 n, float u, float v) {
@@ -581,7 +632,8 @@ struct Loader {
         else if (o->type == "prbvolpath") I.type = LRT_INTEGRATOR_PRBVOLPATH;
         else if (o->type == "biovolpath") I.type = LRT_INTEGRATOR_BIOVOLPATH;
         else if (o->type == "biovolpath06") I.type = LRT_INTEGRATOR_BIOVOLPATH06;
-        else fail("unsupported integrator \"" + o->type + "\" (supported: path, volpath, prbvolpath, biovolpath, biovolpath06)");
+        else if (o->type == "volpathmis") I.type = LRT_INTEGRATOR_VOLPATHMIS;
+        else fail("unsupported integrator \"" + o->type + "\" (supported: path, volpath, volpathmis, prbvolpath, biovolpath, biovolpath06)");
         // src/render/integrator.cpp:535-552
         I.max_depth = get_int(*o, "max_depth", -1); I.rr_depth = get_int(*o, "rr_depth", 5); I.hide_emitters = get_bool(*o, "hide_emitters", false);
         if (I.max_depth < 0 && I.max_depth != -1) fail("\"max_depth\" must be set to -1 (infinite) or a value >= 0");

@@ -29,6 +29,14 @@ extern "C" orc_scene *orc_scene_create(const lrt_scene_desc *desc) {
         }
     }
     S.media.assign(desc->media, desc->media + desc->n_media);
+    S.meddata.resize(desc->n_media);
+    for (uint32_t i = 0; i < desc->n_media; ++i) {
+        lrt_medium_desc &M = S.media[i];
+        if (M.type == LRT_MEDIUM_HETEROGENEOUS && M.grid_data) {
+            S.meddata[i].assign(M.grid_data, M.grid_data + (size_t) M.grid_res[0] * M.grid_res[1] * M.grid_res[2]);
+            M.grid_data = S.meddata[i].data();
+        }
+    }
     S.emitters.assign(desc->emitters, desc->emitters + desc->n_emitters);
     S.emdata.resize(desc->n_emitters);
     for (uint32_t i = 0; i < desc->n_emitters; ++i) {

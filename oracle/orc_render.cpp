@@ -466,10 +466,68 @@ static inline float idx3(V3 v, uint32_t c) { return c == 0 ? v.x : (c == 1 ? v.y
 struct MI { float t; V3 p, wi; V3 sigma_s, sigma_n, sigma_t, combined; float mint; int medium;
             bool valid() const { return t != kInf; } };
 
-/* src/render/medium.cpp:40-82 + src/media/homogeneous.cpp:153-181 */
+/* src/volumes/grid.cpp interpolate_1 through Dr.Jit's Texture3f::eval (un-vendored; trilinear, clamp): texel centres at
+   (i + .5) / res; lerp along x, then y, then z, each as fmadd(w0, a, w1 * b).  p_local in the grid's unit cube. */
+static float grid_eval(const lrt_medium_desc &M, V3 pl) {
+    const int rx = M.grid_res[0], ry = M.grid_res[1], rz = M.grid_res[2];
+    float fx = fmaf(pl.x, (float) rx, -.5f), fy = fmaf(pl.y, (float) ry, -.5f), fz = fmaf(pl.z, (float) rz, -.5f);
+    float flx = floorf(fx), fly = floorf(fy), flz = floorf(fz);
+    float w1x = fx - flx, w1y = fy - fly, w1z = fz - flz, w0x = 1.f - w1x, w0y = 1.f - w1y, w0z = 1.f - w1z;
+    auto cl = [](float v, int n) { int i = (v < -2e9f) ? -2000000000 : (v > 2e9f ? 2000000000 : (int) v); return i < 0 ? 0 : (i > n - 1 ? n - 1 : i); };
+    int x0 = cl(flx, rx), x1 = cl(flx + 1.f, rx), y0 = cl(fly, ry), y1 = cl(fly + 1.f, ry), z0 = cl(flz, rz), z1 = cl(flz + 1.f, rz);
+    auto at = [&](int x, int y, int z) { return M.grid_data[((size_t) z * ry + y) * rx + x]; };
+    float c00 = fmaf(w0x, at(x0, y0, z0), w1x * at(x1, y0, z0)), c10 = fmaf(w0x, at(x0, y1, z0), w1x * at(x1, y1, z0));
+    float c01 = fmaf(w0x, at(x0, y0, z1), w1x * at(x1, y0, z1)), c11 = fmaf(w0x, at(x0, y1, z1), w1x * at(x1, y1, z1));
+    float c0 = fmaf(w0y, c00, w1y * c10), c1 = fmaf(w0y, c01, w1y * c11);
+    return fmaf(w0z, c0, w1z * c1);
+}
+
+/* include/mitsuba/core/bbox.h:303-340 ray_intersect (Williams et al.) */
+static bool bbox_ray_intersect(const float lo[3], const float hi[3], const Ray &ray, float *mint, float *maxt) {
+    bool active = ray.d.x != 0.f || ray.d.y != 0.f || ray.d.z != 0.f;
+    float dr[3] = { rcp(ray.d.x), rcp(ray.d.y), rcp(ray.d.z) }, o[3] = { ray.o.x, ray.o.y, ray.o.z }, tmin[3], tmax[3];
+    for (int a = 0; a < 3; ++a) { bool pos = dr[a] >= 0.f; tmin[a] = ((pos ? lo[a] : hi[a]) - o[a]) * dr[a]; tmax[a] = ((pos ? hi[a] : lo[a]) - o[a]) * dr[a]; }
+    auto max_safe = [](float a, float b) { return (a > b || !std::isfinite(b)) ? a : b; };
+    auto min_safe = [](float a, float b) { return (a < b || !std::isfinite(b)) ? a : b; };
+    active = active && !((tmin[0] > tmax[1]) || (tmin[1] > tmax[0]));
+    tmin[0] = max_safe(tmin[0], tmin[1]); tmax[0] = min_safe(tmax[0], tmax[1]);
+    active = active && !((tmin[0] > tmax[2]) || (tmin[2] > tmax[0]));
+    tmin[0] = max_safe(tmin[0], tmin[2]); tmax[0] = min_safe(tmax[0], tmax[2]);
+    *mint = tmin[0]; *maxt = tmax[0];
+    return active;
+}
+
+static inline bool medium_is_homogeneous(const lrt_medium_desc &M) { return M.type != LRT_MEDIUM_HETEROGENEOUS; }
+
+/* src/render/medium.cpp:40-82 with src/media/homogeneous.cpp:153-181 or src/media/heterogeneous.cpp:178-200 */
 static MI medium_sample_interaction(const Scene &S, int m, const Ray &ray, float sample, uint32_t channel) {
     const lrt_medium_desc &M = S.media[m];
     MI mei; mei.wi = -ray.d; mei.medium = m;
+    V3 albedo(M.albedo[0], M.albedo[1], M.albedo[2]);
+    if (M.type == LRT_MEDIUM_HETEROGENEOUS) {
+        float mint, maxt;
+        bool active = bbox_ray_intersect(M.grid_bbox_min, M.grid_bbox_max, ray, &mint, &maxt);
+        active = active && (std::isfinite(mint) || std::isfinite(maxt));
+        if (!active) { mint = 0.f; maxt = kInf; }
+        mint = fmaxf(0.f, mint); maxt = fminf(ray.maxt, maxt);
+        const float max_density = M.scale * M.grid_max;                           /* get_majorant: not masked */
+        float sampled_t = mint + (-m_log(1.f - sample) / max_density);
+        bool valid = active && sampled_t <= maxt;
+        mei.t = valid ? sampled_t : kInf;
+        mei.p = fma3(ray.d, sampled_t, ray.o);
+        mei.mint = mint;
+        float st = 0.f;
+        if (valid) {
+            const float *t = M.grid_to_local;
+            V3 pl(fmaf(t[2], mei.p.z, fmaf(t[1], mei.p.y, fmaf(t[0], mei.p.x, t[3]))), fmaf(t[6], mei.p.z, fmaf(t[5], mei.p.y, fmaf(t[4], mei.p.x, t[7]))),
+                  fmaf(t[10], mei.p.z, fmaf(t[9], mei.p.y, fmaf(t[8], mei.p.x, t[11]))));
+            st = M.scale * grid_eval(M, pl);
+        }
+        mei.sigma_t = V3(st); mei.sigma_s = mei.sigma_t * (valid ? albedo : V3(0.f));
+        mei.sigma_n = V3(max_density) - mei.sigma_t;
+        mei.combined = V3(max_density);
+        return mei;
+    }
     float mint = 0.f, maxt = fminf(ray.maxt, kInf);
     V3 sigmat = V3(M.sigma_t[0], M.sigma_t[1], M.sigma_t[2]) * M.scale;
     float mm = idx3(sigmat, channel);
@@ -478,7 +536,6 @@ static MI medium_sample_interaction(const Scene &S, int m, const Ray &ray, float
     mei.t = valid ? sampled_t : kInf;
     mei.p = fma3(ray.d, sampled_t, ray.o);
     mei.mint = mint;
-    V3 albedo(M.albedo[0], M.albedo[1], M.albedo[2]);
     mei.sigma_t = valid ? sigmat : V3(0.f);
     mei.sigma_s = valid ? sigmat * albedo : V3(0.f);
     mei.sigma_n = V3(0.f);
@@ -552,12 +609,12 @@ static V3 volpath_sample_emitter(Ctx &C, V3 ref_p, V3 ref_n, const SI *ref_si, i
         if (active_medium) {
             const lrt_medium_desc &M = S.media[medium];
             MI mei = medium_sample_interaction(S, medium, ray, C.next(), channel);
-            if (mei.valid()) ray.maxt = fminf(mei.t, remaining_dist);
+            if (mei.valid() && medium_is_homogeneous(M)) ray.maxt = fminf(mei.t, remaining_dist);
             bool elide = false;
             if (needs_intersection) {
                 /* the query cannot change the result when the sampled collision is real
                    (sigma_n = 0) and every surface blocks (no null BSDF): both outcomes give 0 */
-                elide = mei.valid() && !S.has_null_bsdf;
+                elide = mei.valid() && !S.has_null_bsdf && medium_is_homogeneous(M);
                 C.n_shadow++; if (!elide) C.n_shadow_needed++;
                 Hit h = S.intersect(ray, false, false);
                 si = S.compute_si(ray, h);
@@ -634,13 +691,13 @@ static void volpath_sample(Ctx &C, Ray ray, int medium, V3 *out, bool *out_valid
         if (!active) break;
 
         bool active_medium = medium >= 0, active_surface = !active_medium;
-        bool act_medium_scatter = false, escaped_medium = false;
+        bool act_medium_scatter = false, escaped_medium = false, act_null_scatter = false;
         MI mei; mei.t = kInf;
         if (!active_medium) C.skip(2);                                /* volpath.cpp:220,239 */
         if (active_medium) {
             const lrt_medium_desc &M = S.media[medium];
             mei = medium_sample_interaction(S, medium, ray, C.next(), channel);
-            if (mei.valid()) ray.maxt = mei.t;
+            if (mei.valid() && medium_is_homogeneous(M)) ray.maxt = mei.t;
             if (needs_intersection) { Hit h = S.intersect(ray, false, false); si = S.compute_si(ray, h); }
             needs_intersection = false;
             if (si.t < mei.t) mei.t = kInf;
@@ -656,16 +713,15 @@ static void volpath_sample(Ctx &C, Ray ray, int medium, V3 *out, bool *out_valid
             if (!active_medium) C.skip(1);                            /* volpath.cpp:239 */
             if (active_medium) {
                 float null_scatter_prob = mean3(mei.sigma_n / mei.combined);
-                bool null_scatter = C.next() < null_scatter_prob;
-                /* homogeneous media: sigma_n = 0, the null branch (volpath.cpp:243-259) is unreachable */
-                (void) null_scatter;
-                act_medium_scatter = true;
-                depth += 1;
-                last_scatter_p = mei.p;
+                act_null_scatter = C.next() < null_scatter_prob;                  /* volpath.cpp:238-246; never true for sigma_n = 0 */
+                act_medium_scatter = !act_null_scatter;
+                if (M.has_spectral_extinction && act_null_scatter) throughput *= mei.sigma_n / null_scatter_prob;
+                if (act_medium_scatter) { depth += 1; last_scatter_p = mei.p; }
             }
         }
         active = active && depth < max_depth;
         act_medium_scatter = act_medium_scatter && active;
+        if (act_null_scatter) { ray.o = mei.p; si.t = si.t - mei.t; }            /* :254-257; the surface found earlier stays in `si` */
         if (!act_medium_scatter) C.skip(3);                           /* volpath.cpp:407 (NEE), 288, 289 */
         if (act_medium_scatter) {
             const lrt_medium_desc &M = S.media[medium];

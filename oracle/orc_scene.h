@@ -48,6 +48,7 @@ struct Scene {
     std::vector<lrt_texture_desc> textures;
     std::vector<std::vector<float>> texdata;
     std::vector<lrt_medium_desc> media;
+    std::vector<std::vector<float>> meddata;
     std::vector<lrt_emitter_desc> emitters;
     std::vector<std::vector<float>> emdata;
 

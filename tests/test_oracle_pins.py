@@ -482,3 +482,75 @@ def test_prb_primal_matches_volpath_in_expectation(mi, orc):
     a = o.render(spp=4096, seed=3, integrator="prbvolpath").astype(np.float64)
     b = o.render(spp=4096, seed=4, integrator="volpath").astype(np.float64)
     assert abs(a.mean() - b.mean()) <= 0.02 * b.mean()
+
+
+# ---- heterogeneous media + null collisions: delta tracking against the homogeneous closed forms ----
+def _het_slab_xml(tmp_path, mi, grid, scale, albedo, spp, max_depth=-1, integrator="volpath", spectral="true"):
+    vol = os.path.join(str(tmp_path), "density.vol")
+    mi.write_volume_grid(vol, grid)
+    # the grid's unit cube is mapped onto the cube [-1, 1]^3 that bounds the medium
+    return f"""<scene version="3.0.0">
+      <integrator type="{integrator}"><integer name="max_depth" value="{max_depth}"/></integrator>
+      <sensor type="perspective"><float name="fov" value="2"/>
+        <transform name="to_world"><lookat origin="0, 0, -20" target="0, 0, 0" up="0, 1, 0"/></transform>
+        <sampler type="independent"><integer name="sample_count" value="{spp}"/></sampler>
+        <film type="hdrfilm"><integer name="width" value="8"/><integer name="height" value="8"/><rfilter type="box"/></film>
+      </sensor>
+      <medium type="heterogeneous" id="smoke">
+        <volume name="sigma_t" type="gridvolume"><string name="filename" value="{vol}"/>
+          <transform name="to_world"><scale value="2"/><translate x="-1" y="-1" z="-1"/></transform></volume>
+        <rgb name="albedo" value="{albedo}"/><float name="scale" value="{scale}"/><boolean name="has_spectral_extinction" value="{spectral}"/>
+      </medium>
+      <shape type="cube"><bsdf type="null"/><ref name="interior" id="smoke"/></shape>
+      <emitter type="constant"><rgb name="radiance" value="1, 1, 1"/></emitter>
+    </scene>"""
+
+
+@pytest.mark.parametrize("spectral", ["true", "false"])
+def test_heterogeneous_beer_lambert(mi, orc, tmp_path, spectral):
+    """Absorbing heterogeneous slab: density varies along the viewing axis (z), so the pixel value is exp(-scale * integral of the
+    trilinear grid along the ray); delta tracking with majorant scale * max must reproduce it (volpath.cpp:238-259)."""
+    rz = 16
+    prof = 0.2 + 0.8 * np.sin(np.linspace(0.2, 2.9, rz)) ** 2
+    grid = np.broadcast_to(prof[:, None, None], (rz, 4, 4)).astype(np.float32)
+    scale = 1.3
+    sc = mi.load_string(_het_slab_xml(tmp_path, mi, grid, scale, "0, 0, 0", 8192, spectral=spectral))
+    m = sc.desc.media[0]
+    assert m.type == 4 and list(m.grid_res) == [4, 4, rz] and m.grid_max == pytest.approx(prof.max())
+    assert list(m.grid_bbox_min) == pytest.approx([-1, -1, -1]) and list(m.grid_bbox_max) == pytest.approx([1, 1, 1])
+    img = orc.OrcScene(sc).render().astype(np.float64)[..., :3]
+    # trilinear profile along z through the cube: texel centres at (k + .5) / rz of the unit cube, clamped outside
+    z = (np.linspace(-1, 1, 20001)[:-1] + 1e-4 + 1) / 2
+    f = z * rz - 0.5; k = np.clip(np.floor(f).astype(int), -1, rz - 1); w = f - np.floor(f)
+    dens = prof[np.clip(k, 0, rz - 1)] * (1 - w) + prof[np.clip(k + 1, 0, rz - 1)] * w
+    tau = scale * dens.mean() * 2.0
+    assert img.mean() == pytest.approx(np.exp(-tau), rel=0.03), (img.mean(), np.exp(-tau))
+
+
+def test_heterogeneous_constant_grid_matches_homogeneous(mi, orc, tmp_path):
+    """A constant grid is a homogeneous medium: delta tracking with null collisions (majorant 2.5 x the density, so most collisions
+    are null) must give the homogeneous medium's image in expectation, single scattering included."""
+    sigma, a = 0.6, 0.9
+    grid2 = np.full((6, 6, 6), 0.4, np.float32)
+    sc_het = mi.load_string(_het_slab_xml(tmp_path, mi, grid2, sigma / 0.4, f"{a}, {a}, {a}", 8192, max_depth=2))
+    sc_hom = mi.load_string(_slab_xml(f"{sigma}, {sigma}, {sigma}", f"{a}, {a}, {a}", "volpath", 8192, max_depth=2))
+    het = orc.OrcScene(sc_het).render().astype(np.float64)[..., :3].mean()
+    hom = orc.OrcScene(sc_hom).render().astype(np.float64)[..., :3].mean()
+    assert het == pytest.approx(hom, rel=0.015), (het, hom)
+    # with a loose majorant (a single larger texel OUTSIDE the ray's path) the answer must not move
+    g3 = grid2.copy(); g3[0, 0, 0] = 1.0
+    sc3 = mi.load_string(_het_slab_xml(tmp_path, mi, g3, sigma / 0.4, f"{a}, {a}, {a}", 8192, max_depth=2))
+    o3 = orc.OrcScene(sc3); het3 = o3.render().astype(np.float64)[..., :3].mean()
+    assert het3 == pytest.approx(hom, rel=0.02), (het3, hom)
+    o1 = orc.OrcScene(sc_het); o1.render()
+    assert o3.last_stats["n_iter"] > 1.3 * o1.last_stats["n_iter"]                   # the extra trips are null collisions
+
+
+def test_heterogeneous_furnace(mi, orc, tmp_path):
+    """Albedo 1, radiance-1 environment, varying density: every pixel converges to 1 (energy conservation of the null-collision
+    weights in the spectral branch)."""
+    rng = np.random.default_rng(1)
+    grid = (0.1 + rng.random((8, 8, 8))).astype(np.float32)
+    xml = _het_slab_xml(tmp_path, mi, grid, 2.0, "1, 1, 1", 512).replace('<float name="fov" value="2"/>', '<float name="fov" value="8"/>')
+    img = orc.OrcScene(mi.load_string(xml)).render().astype(np.float64)[..., :3]
+    assert img.mean() == pytest.approx(1.0, abs=0.02)

@@ -109,3 +109,54 @@ def test_liver_singlemesh_bio_reference_render(mi):
     ours, ref = img[inner].mean(0), g[inner].mean(0)
     assert np.allclose(ours, ref, rtol=0.015), (ours / ref)
     assert np.abs(img - g)[inner].mean() < 0.08 * g[inner].mean()
+
+
+def het_xml(vol, sampler="independent", spectral="true", boundary="null", extra_medium="", inside_ref="smoke", md=12):
+    return f"""<scene version="3.0.0">
+  <integrator type="volpath"><integer name="max_depth" value="{md}"/></integrator>
+  <medium type="heterogeneous" id="smoke">
+    <volume name="sigma_t" type="gridvolume"><string name="filename" value="{vol}"/>
+      <transform name="to_world"><scale value="2"/><translate x="-1" y="-1" z="-1"/></transform></volume>
+    <rgb name="albedo" value="0.9, 0.8, 0.6"/><float name="scale" value="3"/><boolean name="has_spectral_extinction" value="{spectral}"/>
+    <phase type="hg"><float name="g" value="0.3"/></phase>
+  </medium>
+  {extra_medium}
+  <sensor type="perspective"><float name="fov" value="40"/>
+    <transform name="to_world"><lookat origin="3, 2.5, 4" target="0, 0, 0" up="0, 1, 0"/></transform>
+    <sampler type="{sampler}"><integer name="sample_count" value="16"/></sampler>
+    <film type="hdrfilm"><integer name="width" value="64"/><integer name="height" value="48"/><rfilter type="box"/></film>
+  </sensor>
+  <shape type="cube"><bsdf type="{boundary}"/><ref name="interior" id="{inside_ref}"/></shape>
+  <shape type="rectangle"><transform name="to_world"><scale value="6"/><rotate x="1" angle="-90"/><translate y="-1.001"/></transform>
+    <bsdf type="diffuse"><texture name="reflectance" type="checkerboard"><transform name="to_uv"><scale x="8" y="8"/></transform></texture></bsdf></shape>
+  <shape type="rectangle"><transform name="to_world"><scale value="0.7"/><rotate x="1" angle="90"/><translate y="3.5"/></transform>
+    <emitter type="area"><rgb name="radiance" value="20, 18, 15"/></emitter></shape>
+  <emitter type="constant"><rgb name="radiance" value="0.3, 0.4, 0.6"/></emitter>
+</scene>"""
+
+
+@pytest.mark.parametrize("case", ["null", "dielectric-ld", "nonspectral", "two-media"])
+def test_heterogeneous_medium_bit_exact(mi, orc, tmp_path, case):
+    """grid-volume medium with delta tracking; null collisions keep the surface interaction found earlier
+    (carried in the record's hit stream), emitter sampling marches through null collisions (volpath.cpp:238-259,468-505)."""
+    rng = np.random.default_rng(3)
+    grid = (0.05 + rng.random((12, 10, 8)) ** 3).astype(np.float32)
+    vol = os.path.join(str(tmp_path), "smoke.vol"); mi.write_volume_grid(vol, grid)
+    kw = {}
+    if case == "null": xml = het_xml(vol)
+    elif case == "dielectric-ld": xml = het_xml(vol, sampler="ldsampler", boundary="dielectric"); kw = dict(max_depth=30, rr_depth=2)
+    elif case == "nonspectral": xml = het_xml(vol, spectral="false"); kw = dict(seed=3)
+    else:
+        hom = '<medium type="homogeneous" id="fog"><rgb name="sigma_t" value="0.5, 0.3, 0.8"/><rgb name="albedo" value="0.8, 0.8, 0.9"/></medium>'
+        xml = het_xml(vol, extra_medium=hom).replace('<shape type="rectangle"><transform name="to_world"><scale value="6"/>',
+            '<shape type="cube"><transform name="to_world"><scale value="0.5"/><translate x="2" y="-0.4"/></transform><bsdf type="null"/><ref name="interior" id="fog"/></shape>'
+            '<shape type="rectangle"><transform name="to_world"><scale value="6"/>')
+    sc = mi.load_string(xml); o = orc.OrcScene(sc)
+    g = assert_lanes_equal(sc, o, 0, 64 * 48 * 16, **kw)
+    assert np.isfinite(g).all() and sc.stats()["n_iter"] > 2 * 64 * 48 * 16
+    raw = sc.render(return_raw=True, **kw)[1]
+    assert film_close(raw, o.render(return_raw=True, **kw)[1]).all()
+    if case == "null":
+        for integ in ("prbvolpath", "biovolpath"):
+            with pytest.raises(RuntimeError, match="heterogeneous|NotImplementedError"):
+                sc.render_samples(0, 64, integrator=integ)
