@@ -188,6 +188,8 @@ typedef struct {
     uint32_t sampler_type;        /* LRT_SAMPLER_*; ld rounds spp up to 4, 16, 64, 256, 1024, ... */
     uint32_t samples_per_pass;    /* integrator `samples_per_pass` (integrator.cpp:176-184), 0: unset; renders of more than
                                      2^32 - 1 samples are split into passes as well (integrator.cpp:275-293)  */
+    uint32_t use_spectral_mis;    /* volpathmis `use_spectral_mis` (volpathmis.cpp:47, default true)                */
+    uint32_t pad;
 } lrt_scene_desc;
 
 /* ----------------------------------------------------------- render call */

@@ -432,6 +432,7 @@ def scene_from_buffers(positions, faces, normals=None, texcoords=None, reflectan
     d.film.width, d.film.height = film; d.film.crop_width, d.film.crop_height = film
     d.film.has_alpha, d.film.rfilter, d.film.rfilter_param = 0, 0, 0.5
     d.integrator.type, d.integrator.max_depth, d.integrator.rr_depth, d.integrator.hide_emitters = _lib.INTEGRATOR[integrator], max_depth, 5, 0
+    d.use_spectral_mis = 1
     d.sample_count, d.sampler_seed = spp, 0
     h = C.c_void_p()
     _lib.check(L.lrt_scene_from_desc(C.byref(d), C.byref(h)))

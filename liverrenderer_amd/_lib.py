@@ -74,7 +74,7 @@ class SceneDesc(C.Structure):
                 ("media", C.POINTER(MediumDesc)), ("emitters", C.POINTER(EmitterDesc)),
                 ("sensor", SensorDesc), ("film", FilmDesc), ("integrator", IntegratorDesc),
                 ("sample_count", C.c_uint32), ("sampler_seed", C.c_uint32),
-                ("sampler_type", C.c_uint32), ("samples_per_pass", C.c_uint32)]
+                ("sampler_type", C.c_uint32), ("samples_per_pass", C.c_uint32), ("use_spectral_mis", C.c_uint32), ("pad", C.c_uint32)]
 
 
 class RenderOpts(C.Structure):

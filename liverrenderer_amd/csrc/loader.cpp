@@ -640,6 +640,7 @@ struct Loader {
         if (I.rr_depth <= 0) fail("\"rr_depth\" must be set to a value greater than zero!");
         int spass = get_int(*o, "samples_per_pass", -1);                      // src/render/integrator.cpp:22-38 (SamplingIntegrator)
         S.desc.samples_per_pass = spass > 0 ? (uint32_t) spass : 0u;
+        S.desc.use_spectral_mis = get_bool(*o, "use_spectral_mis", true) ? 1u : 0u;     // src/integrators/volpathmis.cpp:47
     }
 
     void run(const std::string &text) {
@@ -648,7 +649,7 @@ struct Loader {
         // defaults first (document order matters only among themselves)
         for (auto &c : root->children) if (c->tag == "default") { std::string k = attr(*c, "name"); if (!vars.count(k)) vars[k] = attr(*c, "value"); }
         S.desc = lrt_scene_desc{};
-        S.desc.integrator = { LRT_INTEGRATOR_PATH, -1, 5, 0 };
+        S.desc.integrator = { LRT_INTEGRATOR_PATH, -1, 5, 0 }; S.desc.use_spectral_mis = 1;
         bool have_sensor = false;
         std::vector<ObjP> objs;
         for (auto &c : root->children) {

@@ -907,6 +907,7 @@ static void path_sample(Ctx &C, Ray ray, V3 *out, bool *out_valid) {
 }
 
 #include "orc_bio.h"
+#include "orc_mis.h"
 
 /* --------------------------------------------------- PRB (prbvolpath.py) */
 /* Gradient accumulators of one lane: d/d sigma_t[3] (w.r.t. the `sigma_t` property, i.e. before `scale`),
@@ -1190,6 +1191,7 @@ static SampleOut render_lane(const Scene &S, const Opts &O, uint64_t lane, orc_s
     else if (O.integrator == LRT_INTEGRATOR_PRBVOLPATH) prb_sample(C, ray, false, V3(0.f), V3(0.f), &L, &valid, nullptr);
     else if (O.integrator == LRT_INTEGRATOR_BIOVOLPATH) biovolpath_sample(C, ray, S.d.sensor.medium, &L, &valid);
     else if (O.integrator == LRT_INTEGRATOR_BIOVOLPATH06) biovolpath06_sample(C, ray, S.d.sensor.medium, &L, &valid);
+    else if (O.integrator == LRT_INTEGRATOR_VOLPATHMIS) { if (S.d.use_spectral_mis) volpathmis_sample<true>(C, ray, S.d.sensor.medium, &L, &valid); else volpathmis_sample<false>(C, ray, S.d.sensor.medium, &L, &valid); }
     else volpath_sample(C, ray, S.d.sensor.medium, &L, &valid);
     if (st) { st->n_iter += C.n_iter; st->n_shadow += C.n_shadow; st->n_shadow_needed += C.n_shadow_needed; st->n_samples += 1; }
     if (carry) carry[lane] = C.smp.rng.state;

@@ -554,3 +554,43 @@ def test_heterogeneous_furnace(mi, orc, tmp_path):
     xml = _het_slab_xml(tmp_path, mi, grid, 2.0, "1, 1, 1", 512).replace('<float name="fov" value="2"/>', '<float name="fov" value="8"/>')
     img = orc.OrcScene(mi.load_string(xml)).render().astype(np.float64)[..., :3]
     assert img.mean() == pytest.approx(1.0, abs=0.02)
+
+
+# ---- volpathmis: same expectations as volpath, on the scenes whose answers are known ----
+@pytest.mark.parametrize("smis", ["true", "false"])
+def test_volpathmis_known_answers(mi, orc, smis):
+    """volpathmis (volpathmis.cpp:127-699) estimates the same integral as volpath: Beer-Lambert through a spectrally varying
+    absorber, the single-scattering closed form of test_single_scattering_closed_form, the albedo-1 furnace."""
+    def xml(sigma_t, albedo, spp, max_depth=-1):
+        return _slab_xml(sigma_t, albedo, "volpathmis", spp, max_depth).replace('<integer name="max_depth"', f'<boolean name="use_spectral_mis" value="{smis}"/><integer name="max_depth"')
+    sig = np.array([0.3, 0.8, 1.4])
+    sc = mi.load_string(xml("0.3, 0.8, 1.4", "0, 0, 0", 4096))
+    assert sc.desc.integrator.type == 5 and sc.desc.use_spectral_mis == (1 if smis == "true" else 0)
+    img = orc.OrcScene(sc).render().astype(np.float64)[..., :3]
+    assert np.allclose(img.mean((0, 1)), np.exp(-2 * sig), rtol=0.02), (img.mean((0, 1)), np.exp(-2 * sig))
+    sigma, a = 0.6, 0.9
+    mis = orc.OrcScene(mi.load_string(xml(f"{sigma}, {sigma}, {sigma}", f"{a}, {a}, {a}", 8192, max_depth=2))).render().astype(np.float64)[..., :3].mean()
+    ref = orc.OrcScene(mi.load_string(_slab_xml(f"{sigma}, {sigma}, {sigma}", f"{a}, {a}, {a}", "volpath", 8192, max_depth=2))).render().astype(np.float64)[..., :3].mean()
+    assert mis == pytest.approx(ref, rel=0.015), (mis, ref)
+    furn = orc.OrcScene(mi.load_string(xml("1.5, 0.7, 2.0", "1, 1, 1", 512).replace('<float name="fov" value="2"/>', '<float name="fov" value="8"/>'))).render().astype(np.float64)[..., :3]
+    assert furn.mean() == pytest.approx(1.0, abs=0.02)
+
+
+def test_volpathmis_matches_volpath_on_a_lit_scene(mi, orc, tmp_path):
+    """Surfaces, area light, environment, a heterogeneous medium with null collisions and a coloured homogeneous one: image means
+    of volpathmis (both settings) and volpath agree within Monte-Carlo noise."""
+    from test_round2_gpu import het_xml
+    rng = np.random.default_rng(3)
+    grid = (0.05 + rng.random((12, 10, 8)) ** 3).astype(np.float32)
+    vol = os.path.join(str(tmp_path), "smoke.vol"); mi.write_volume_grid(vol, grid)
+    hom = '<medium type="homogeneous" id="fog"><rgb name="sigma_t" value="0.9, 0.3, 1.6"/><rgb name="albedo" value="0.8, 0.8, 0.9"/></medium>'
+    base = het_xml(vol, extra_medium=hom, md=8).replace('<shape type="rectangle"><transform name="to_world"><scale value="6"/>',
+        '<shape type="cube"><transform name="to_world"><scale value="0.5"/><translate x="2" y="-0.4"/></transform><bsdf type="null"/><ref name="interior" id="fog"/></shape>'
+        '<shape type="rectangle"><transform name="to_world"><scale value="6"/>').replace('<integer name="sample_count" value="16"/>', '<integer name="sample_count" value="256"/>')
+    means = {}
+    for name, integ in (("volpath", '<integrator type="volpath">'), ("mis", '<integrator type="volpathmis">'),
+                        ("mis-nospectral", '<integrator type="volpathmis"><boolean name="use_spectral_mis" value="false"/>')):
+        img = orc.OrcScene(mi.load_string(base.replace('<integrator type="volpath">', integ))).render().astype(np.float64)[..., :3]
+        means[name] = img.mean((0, 1))
+    assert np.allclose(means["mis"], means["volpath"], rtol=0.03), means
+    assert np.allclose(means["mis-nospectral"], means["volpath"], rtol=0.03), means
