@@ -53,7 +53,7 @@ struct DeviceScene {
     std::vector<hipEvent_t> ev_pool;
     std::vector<DMedium> h_media; DMedium *d_media = nullptr;
     std::vector<DBioMedium> h_bio; DBioMedium *d_bio = nullptr;
-    std::vector<DHetMedium> h_het; DHetMedium *d_het = nullptr; std::vector<float *> het_data; bool has_het = false, has_non_bio = false;
+    std::vector<DHetMedium> h_het; DHetMedium *d_het = nullptr; std::vector<float *> het_data; bool has_het = false, has_non_bio = false, need_mis = false, mis_alloc = false;
     DLdsInfo lds{}; bool use_lds = false; int n_cus = 256;
 
     template <typename T> T *track(T *p) { allocs.push_back((void *) p); return p; }
@@ -257,6 +257,8 @@ DeviceScene *device_scene_create(const lrt_scene_desc &d, int device) {
             LRT_SMEM((k_render<LRT_INTEGRATOR_BIOVOLPATH, 1024, true, false>)); LRT_SMEM((k_render<LRT_INTEGRATOR_BIOVOLPATH, 1024, true, true>));
             LRT_SMEM((k_render<LRT_INTEGRATOR_BIOVOLPATH06, 1024, true, false>)); LRT_SMEM((k_render<LRT_INTEGRATOR_BIOVOLPATH06, 1024, true, true>));
             LRT_SMEM((k_render<LRT_INTEGRATOR_VOLPATH_HET, 1024, true, false>)); LRT_SMEM((k_render<LRT_INTEGRATOR_VOLPATH_HET, 1024, true, true>));
+            LRT_SMEM((k_render<LRT_INTEGRATOR_VOLPATHMIS, 1024, true, false>)); LRT_SMEM((k_render<LRT_INTEGRATOR_VOLPATHMIS, 1024, true, true>));
+            LRT_SMEM((k_render<LRT_INTEGRATOR_VOLPATHMIS_PLAIN, 1024, true, false>)); LRT_SMEM((k_render<LRT_INTEGRATOR_VOLPATHMIS_PLAIN, 1024, true, true>));
             LRT_SMEM((k_render_prb<false, 1024, true, false>)); LRT_SMEM((k_render_prb<true, 1024, true, false>));
             LRT_SMEM((k_render_prb<false, 1024, true, true>)); LRT_SMEM((k_render_prb<true, 1024, true, true>));
             LRT_SMEM((k_trace_lds<true>)); LRT_SMEM((k_trace_lds<false>));
@@ -420,9 +422,10 @@ void device_scene_update_params(DeviceScene *D, const lrt_scene_desc &d) {
 }
 
 static void ensure_workspace(DeviceScene *D, uint32_t capacity) {
-    if (D->capacity >= capacity) return;
+    if (D->capacity >= capacity && D->mis_alloc == D->need_mis) return;
+    D->mis_alloc = D->need_mis;
     auto alloc_q = [&](DPathStreams &q) {
-        D->release(q.o_maxt); D->release(q.d_eta); D->release(q.tp_pdf); D->release(q.res_flags); D->release(q.lp_lane); D->release(q.rng); D->release(q.tdepth); D->release(q.hit); q.hit = nullptr;
+        D->release(q.o_maxt); D->release(q.d_eta); D->release(q.tp_pdf); D->release(q.res_flags); D->release(q.lp_lane); D->release(q.rng); D->release(q.tdepth); D->release(q.hit); q.hit = nullptr; D->release(q.w1); D->release(q.w2); D->release(q.w3); D->release(q.w4); q.w1 = q.w2 = q.w3 = q.w4 = nullptr;
         HIP_CHECK(hipMalloc((void **) &q.o_maxt, (size_t) capacity * 16)); D->track(q.o_maxt);
         HIP_CHECK(hipMalloc((void **) &q.d_eta, (size_t) capacity * 16)); D->track(q.d_eta);
         HIP_CHECK(hipMalloc((void **) &q.tp_pdf, (size_t) capacity * 16)); D->track(q.tp_pdf);
@@ -430,7 +433,8 @@ static void ensure_workspace(DeviceScene *D, uint32_t capacity) {
         HIP_CHECK(hipMalloc((void **) &q.lp_lane, (size_t) capacity * 16)); D->track(q.lp_lane);
         HIP_CHECK(hipMalloc((void **) &q.rng, (size_t) capacity * 8)); D->track(q.rng);
         HIP_CHECK(hipMalloc((void **) &q.tdepth, (size_t) capacity * 4)); D->track(q.tdepth);
-        if (D->has_het) { HIP_CHECK(hipMalloc((void **) &q.hit, (size_t) capacity * 16)); D->track(q.hit); }
+        if (D->has_het || D->need_mis) { HIP_CHECK(hipMalloc((void **) &q.hit, (size_t) capacity * 16)); D->track(q.hit); }
+        if (D->need_mis) for (float4 **w : { &q.w1, &q.w2, &q.w3, &q.w4 }) { HIP_CHECK(hipMalloc((void **) w, (size_t) capacity * 16)); D->track(*w); }
     };
     HIP_CHECK(hipStreamSynchronize(D->stream));
     alloc_q(D->q[0]); alloc_q(D->q[1]);
@@ -585,7 +589,7 @@ static void check_integrator_media(DeviceScene *D, int integrator) {
     if ((integrator == LRT_INTEGRATOR_BIOVOLPATH || integrator == LRT_INTEGRATOR_BIOVOLPATH06) && D->has_non_bio)
         throw std::runtime_error("NotImplementedError: sample_interaction (the bio integrators need liver / parenchyma / glissonCapsule media)");
     if (integrator == LRT_INTEGRATOR_PRBVOLPATH && D->has_het) throw std::runtime_error("unsupported: prbvolpath with heterogeneous media");
-    if (integrator == LRT_INTEGRATOR_VOLPATHMIS) throw std::runtime_error("unsupported integrator: volpathmis is not implemented on the device yet");
+    if (integrator == LRT_INTEGRATOR_VOLPATHMIS) D->need_mis = true;          // its wider path record is allocated on first use
 }
 
 // One persistent launch per render (k_render / k_render_prb): per-workgroup path pools, in-kernel regeneration; see
@@ -622,6 +626,7 @@ static void run_wavefront(DeviceScene *D, const lrt_scene_desc &d, const Resolve
             case LRT_INTEGRATOR_PATH: LRT_LAUNCH(LRT_INTEGRATOR_PATH, BS, LDSB); break; \
             case LRT_INTEGRATOR_BIOVOLPATH: LRT_LAUNCH(LRT_INTEGRATOR_BIOVOLPATH, BS, LDSB); break; \
             case LRT_INTEGRATOR_BIOVOLPATH06: LRT_LAUNCH(LRT_INTEGRATOR_BIOVOLPATH06, BS, LDSB); break; \
+            case LRT_INTEGRATOR_VOLPATHMIS: if (d.use_spectral_mis) LRT_LAUNCH(LRT_INTEGRATOR_VOLPATHMIS, BS, LDSB); else LRT_LAUNCH(LRT_INTEGRATOR_VOLPATHMIS_PLAIN, BS, LDSB); break; \
             default: if (D->has_het) LRT_LAUNCH(LRT_INTEGRATOR_VOLPATH_HET, BS, LDSB); else LRT_LAUNCH(LRT_INTEGRATOR_VOLPATH, BS, LDSB); } } while (0)
         if (D->use_lds) LRT_LAUNCH_I(1024, true); else LRT_LAUNCH_I(LRT_BLOCK, false);
         #undef LRT_LAUNCH_I

@@ -158,12 +158,15 @@ struct DPathStreams {
     float4 *lp_lane;           // last scatter position, lane id (bits)
     uint2  *rng;               // PCG32 state
     float  *tdepth;            // biovolpath / biovolpath06 only: the loop state `tissueDepth`
-    float4 *hit;               // volpath with heterogeneous media only: the surface interaction a null collision keeps (t, u, v, prim)
+    float4 *hit;               // volpath with heterogeneous media / volpathmis: the surface interaction a null collision keeps (t, u, v, prim)
+    float4 *w1, *w2, *w3, *w4; // volpathmis only: with tp_pdf, the 18 floats of p_over_f and p_over_f_nee
 };
 #define LRT_STATE_BYTES 88     // bytes per path record across all streams (path / volpath)
+#define LRT_STATE_BYTES_MIS 168 // volpathmis: o, d, res, lp, rng, hit + five float4 of MIS weights
 #define LRT_STATE_BYTES_HET 104 // volpath with heterogeneous media: + the kept surface hit (float4)
 #define LRT_STATE_BYTES_BIO 92 // biovolpath*: + tissueDepth; the maxt slot carries the previous ray query's distance
 
+#define LRT_INTEGRATOR_VOLPATHMIS_PLAIN 102   // kernel selector: volpathmis with use_spectral_mis = false
 #define LRT_INTEGRATOR_VOLPATH_HET 101   // kernel selector (not an API value): volpath on a scene with heterogeneous media
 
 // flag word layout
@@ -176,6 +179,7 @@ struct DPathStreams {
 #define PF_NOHIT        (1u << 28)     // look-ahead proved that the next free-flight segment reaches no surface
 #define PF_BIO_SCATTERED (1u << 29)    // biovolpath06: scattered_chain
 #define PF_HAVE_SI      (1u << 29)     // volpath, heterogeneous media: needs_intersection == false, the record's hit stream holds `si`
+#define PF_LAST_NULL    (1u << 30)     // volpathmis: last_event_was_null
 #define PF_BIO_EMIT     (1u << 30)     // biovolpath06: type & 0x0001 (EmittedRadiance)
 #define PF_BIO_FULL     (1u << 31)     // biovolpath06: type & 0x0004 and type & 0x0008 (they only appear together)
 

@@ -19,11 +19,12 @@ struct PathState {
     V3 o, d, tp, res, lp; float maxt, eta, last_pdf; uint32_t flags, lane; uint64_t rng_state;
     float tdepth, si_t;        // biovolpath / biovolpath06: `tissueDepth`, distance returned by the previous trip's ray query
     float4 hit;                // volpath, heterogeneous media: the surface hit (t, u, v, prim) a null collision keeps (PF_HAVE_SI)
+    float W[2][3][3];          // volpathmis: p_over_f, p_over_f_nee
 };
 
 // BIO: a queued path's ray always comes from spawn_ray (maxt = largest float), so its maxt slot carries si_t instead, and
 // the seventh stream holds tissueDepth (92 B records)
-// MODE: 0 path / volpath (88 B), 1 biovolpath* (92 B), 2 volpath with heterogeneous media (104 B)
+// MODE: 0 path / volpath (88 B), 1 biovolpath* (92 B), 2 volpath with heterogeneous media (104 B), 3 volpathmis (168 B)
 template <int MODE = 0, typename QS>
 DEV void load_state(const QS &q, size_t i, PathState &s) {
     float4 a = q.o_maxt[i], b = q.d_eta[i], c = q.tp_pdf[i], d = q.res_flags[i], e = q.lp_lane[i]; uint2 r = q.rng[i];
@@ -31,18 +32,28 @@ DEV void load_state(const QS &q, size_t i, PathState &s) {
     s.tp = V3(c.x, c.y, c.z); s.last_pdf = c.w; s.res = V3(d.x, d.y, d.z); s.flags = f2u(d.w);
     s.lp = V3(e.x, e.y, e.z); s.lane = f2u(e.w); s.rng_state = ((uint64_t) r.y << 32) | r.x;
     if (MODE == 1) { s.si_t = a.w; s.maxt = kLargest; s.tdepth = q.tdepth[i]; }
-    if (MODE == 2) s.hit = q.hit[i];
+    if (MODE == 2 || MODE == 3) s.hit = q.hit[i];
+    if (MODE == 3) {
+        const float4 w1 = q.w1[i], w2 = q.w2[i], w3 = q.w3[i], w4 = q.w4[i];
+        float *W = &s.W[0][0][0];
+        W[0] = c.x; W[1] = c.y; W[2] = c.z; W[3] = c.w; W[4] = w1.x; W[5] = w1.y; W[6] = w1.z; W[7] = w1.w; W[8] = w2.x;
+        W[9] = w2.y; W[10] = w2.z; W[11] = w2.w; W[12] = w3.x; W[13] = w3.y; W[14] = w3.z; W[15] = w3.w; W[16] = w4.x; W[17] = w4.y;
+    }
 }
 template <int MODE = 0, typename QS>
 DEV void store_state(const QS &q, size_t i, const PathState &s) {
     q.o_maxt[i] = make_float4(s.o.x, s.o.y, s.o.z, MODE == 1 ? s.si_t : s.maxt);
     q.d_eta[i] = make_float4(s.d.x, s.d.y, s.d.z, s.eta);
-    q.tp_pdf[i] = make_float4(s.tp.x, s.tp.y, s.tp.z, s.last_pdf);
+    if (MODE == 3) {
+        const float *W = &s.W[0][0][0];
+        q.tp_pdf[i] = make_float4(W[0], W[1], W[2], W[3]); q.w1[i] = make_float4(W[4], W[5], W[6], W[7]); q.w2[i] = make_float4(W[8], W[9], W[10], W[11]);
+        q.w3[i] = make_float4(W[12], W[13], W[14], W[15]); q.w4[i] = make_float4(W[16], W[17], 0.f, 0.f);
+    } else q.tp_pdf[i] = make_float4(s.tp.x, s.tp.y, s.tp.z, s.last_pdf);
     q.res_flags[i] = make_float4(s.res.x, s.res.y, s.res.z, u2f(s.flags));
     q.lp_lane[i] = make_float4(s.lp.x, s.lp.y, s.lp.z, u2f(s.lane));
     q.rng[i] = make_uint2((uint32_t) s.rng_state, (uint32_t) (s.rng_state >> 32));
     if (MODE == 1) q.tdepth[i] = s.tdepth;
-    if (MODE == 2) q.hit[i] = s.hit;
+    if (MODE == 2 || MODE == 3) q.hit[i] = s.hit;
 }
 
 // Sampler::seed in the JIT branch of SamplingIntegrator::render (integrator.cpp:308-311): independent: TEA4(base + seed,
@@ -130,7 +141,9 @@ DEV PathState generate_camera_path(SceneRef sc, RpRef rp, const uint32_t *__rest
     Ray ray = camera_ray(sc, fma_(spx, sc.film.scale_x, sc.film.offset_x), fma_(spy, sc.film.scale_y, sc.film.offset_y));
     PathState s;
     s.o = ray.o; s.d = ray.d; s.maxt = ray.maxt; s.eta = 1.f; s.tp = V3(1.f); s.res = V3(0.f); s.lp = V3(0.f); s.last_pdf = 1.f; s.lane = lane;
-    s.tdepth = 0.f; s.si_t = kInf; s.hit = make_float4(0.f, 0.f, 0.f, 0.f);                                                   // biovolpath.cpp:125,129: si = zeros (t = inf), tissueDepth = 0
+    s.tdepth = 0.f; s.si_t = kInf; s.hit = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int a = 0; a < 2; ++a) for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) s.W[a][i][j] = 1.f;         // volpathmis.cpp:158-159
+                                                     // biovolpath.cpp:125,129: si = zeros (t = inf), tissueDepth = 0
     bool env_visible = !rp.hide_emitters && sc.env.type >= 0;
     uint32_t flags = env_visible ? PF_VALID : 0u;
     if (rp.integrator == LRT_INTEGRATOR_PATH) flags |= PF_SPECULAR;                 // prev_bsdf_delta = true
@@ -632,6 +645,7 @@ DEV bool path_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, const TR 
 
 } // namespace lrt
 #include "kernels_bio.h"
+#include "kernels_mis.h"
 namespace lrt {
 
 // ---- the render kernel.  ONE launch per lrt_render: every workgroup is persistent and owns a private pool of path records
@@ -649,7 +663,7 @@ namespace lrt {
 // n_a + n_b + n_c <= P, so the regions never collide.  No cross-workgroup dependency exists besides the lane ticket and the
 // film atomics; every wave leaves its loops once the ticket is exhausted and its pool is empty.
 template <typename QS> DEV DPathStreams offset_streams(const QS &q, size_t off) {
-    DPathStreams r; r.o_maxt = q.o_maxt + off; r.d_eta = q.d_eta + off; r.tp_pdf = q.tp_pdf + off; r.res_flags = q.res_flags + off; r.lp_lane = q.lp_lane + off; r.rng = q.rng + off; r.tdepth = q.tdepth + off; r.hit = q.hit + off;
+    DPathStreams r; r.o_maxt = q.o_maxt + off; r.d_eta = q.d_eta + off; r.tp_pdf = q.tp_pdf + off; r.res_flags = q.res_flags + off; r.lp_lane = q.lp_lane + off; r.rng = q.rng + off; r.tdepth = q.tdepth + off; r.hit = q.hit + off; r.w1 = q.w1 + off; r.w2 = q.w2 + off; r.w3 = q.w3 + off; r.w4 = q.w4 + off;
     return r;
 }
 
@@ -688,7 +702,7 @@ k_render(ScenePtr scp, LaunchPtr lp) {
     __shared__ uint32_t s_in[3], s_out[3], s_ticket, s_fresh;
     __shared__ unsigned long long s_fresh_base, s_prof[8];
     const uint32_t tid = threadIdx.x, lane_in_wave = tid & 63u;
-    constexpr int MODE = (INTEGRATOR == LRT_INTEGRATOR_BIOVOLPATH || INTEGRATOR == LRT_INTEGRATOR_BIOVOLPATH06) ? 1 : (INTEGRATOR == LRT_INTEGRATOR_VOLPATH_HET ? 2 : 0);
+    constexpr int MODE = (INTEGRATOR == LRT_INTEGRATOR_BIOVOLPATH || INTEGRATOR == LRT_INTEGRATOR_BIOVOLPATH06) ? 1 : (INTEGRATOR == LRT_INTEGRATOR_VOLPATH_HET ? 2 : ((INTEGRATOR == LRT_INTEGRATOR_VOLPATHMIS || INTEGRATOR == LRT_INTEGRATOR_VOLPATHMIS_PLAIN) ? 3 : 0));
     if (tid < 8) s_prof[tid] = 0;
     LdsScene L{};
     if (LDS_BVH) {
@@ -757,6 +771,8 @@ k_render(ScenePtr scp, LaunchPtr lp) {
                 if (INTEGRATOR == LRT_INTEGRATOR_PATH) alive = LDS_BVH ? path_iteration(sc, rp, s, rng, tr_lds, n_shadow) : path_iteration(sc, rp, s, rng, tr_glb, n_shadow);
                 else if (INTEGRATOR == LRT_INTEGRATOR_BIOVOLPATH) alive = LDS_BVH ? biovolpath_iteration(sc, rp, s, rng, tr_lds, n_shadow, n_extra) : biovolpath_iteration(sc, rp, s, rng, tr_glb, n_shadow, n_extra);
                 else if (INTEGRATOR == LRT_INTEGRATOR_BIOVOLPATH06) alive = LDS_BVH ? biovolpath06_iteration(sc, rp, s, rng, tr_lds) : biovolpath06_iteration(sc, rp, s, rng, tr_glb);
+                else if (INTEGRATOR == LRT_INTEGRATOR_VOLPATHMIS) alive = LDS_BVH ? volpathmis_iteration<true>(sc, rp, s, rng, tr_lds, n_shadow) : volpathmis_iteration<true>(sc, rp, s, rng, tr_glb, n_shadow);
+                else if (INTEGRATOR == LRT_INTEGRATOR_VOLPATHMIS_PLAIN) alive = LDS_BVH ? volpathmis_iteration<false>(sc, rp, s, rng, tr_lds, n_shadow) : volpathmis_iteration<false>(sc, rp, s, rng, tr_glb, n_shadow);
                 else if (INTEGRATOR == LRT_INTEGRATOR_VOLPATH_HET) alive = LDS_BVH ? volpath_iteration<true>(sc, rp, s, rng, tr_lds, n_shadow, n_extra) : volpath_iteration<true>(sc, rp, s, rng, tr_glb, n_shadow, n_extra);
                 else alive = LDS_BVH ? volpath_iteration<false>(sc, rp, s, rng, tr_lds, n_shadow, n_extra) : volpath_iteration<false>(sc, rp, s, rng, tr_glb, n_shadow, n_extra);
                 s.rng_state = rng.state;

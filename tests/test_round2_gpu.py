@@ -160,3 +160,33 @@ def test_heterogeneous_medium_bit_exact(mi, orc, tmp_path, case):
         for integ in ("prbvolpath", "biovolpath"):
             with pytest.raises(RuntimeError, match="heterogeneous|NotImplementedError"):
                 sc.render_samples(0, 64, integrator=integ)
+
+
+@pytest.mark.parametrize("smis", ["true", "false"])
+def test_volpathmis_bit_exact(mi, orc, tmp_path, smis):
+    """volpathmis (volpathmis.cpp:127-699) on the device against the oracle: weight matrices in the path record, null collisions,
+    emitter sampling with both weight sets, hide_emitters, ld sampler, the liver scene."""
+    from conftest import LIVER_XML
+    integ = f'<integrator type="volpathmis"><boolean name="use_spectral_mis" value="{smis}"/>'
+    rng = np.random.default_rng(3)
+    grid = (0.05 + rng.random((12, 10, 8)) ** 3).astype(np.float32)
+    vol = os.path.join(str(tmp_path), "smoke.vol"); mi.write_volume_grid(vol, grid)
+    hom = '<medium type="homogeneous" id="fog"><rgb name="sigma_t" value="0.9, 0.3, 1.6"/><rgb name="albedo" value="0.8, 0.8, 0.9"/><boolean name="has_spectral_extinction" value="false"/></medium>'
+    two = het_xml(vol, extra_medium=hom).replace('<shape type="rectangle"><transform name="to_world"><scale value="6"/>',
+        '<shape type="cube"><transform name="to_world"><scale value="0.5"/><translate x="2" y="-0.4"/></transform><bsdf type="null"/><ref name="interior" id="fog"/></shape>'
+        '<shape type="rectangle"><transform name="to_world"><scale value="6"/>')
+    scenes = [(fog_xml(), {}), (fog_xml(rf="box", sensor_medium='<ref id="haze"/>', exterior='<ref name="exterior" id="haze"/>', md="8"), dict(seed=2)),
+              (two, dict(rr_depth=2)), (het_xml(vol, sampler="ldsampler", boundary="dielectric"), dict(max_depth=20)),
+              (fog_xml(env='<emitter type="constant"><rgb name="radiance" value="0.3, 0.4, 0.6"/></emitter>', rf="box"), dict(hide_emitters=True, max_depth=4))]
+    for xml, kw in scenes:
+        sc = mi.load_string(xml.replace('<integrator type="volpath">', integ)); o = orc.OrcScene(sc)
+        h, w, _ = sc.film_shape()
+        g = assert_lanes_equal(sc, o, 0, w * h * sc.spp, **kw)
+        assert np.isfinite(g).all()
+    raw = sc.render(return_raw=True)[1]
+    assert film_close(raw, o.render(return_raw=True)[1]).all()
+    d = mi.cornell_box(); d['integrator'] = {'type': 'volpathmis', 'max_depth': 6, 'use_spectral_mis': smis == "true"}
+    d['sensor']['film'].update({'width': 64, 'height': 64}); d['sensor']['sampler']['sample_count'] = 8
+    for s in (mi.load_dict(d), mi.load_file(LIVER_XML, integrator="volpathmis", spp=8, res_width=192, res_height=108)):
+        h, w, _ = s.film_shape()
+        assert_lanes_equal(s, orc.OrcScene(s), 0, w * h * 8)
