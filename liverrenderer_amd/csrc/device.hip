@@ -171,6 +171,17 @@ __global__ void k_bio_prepare(DBioMedium *bio, uint32_t n) {
     if (i < n) bio[i].log10_hep = m_log2(bio[i].hepatocity + 1.f) / m_log2(10.f);
 }
 
+// Per-medium constants of the real-scattering weight (volpath.cpp:261-265), evaluated once with the device's own arithmetic:
+// sigma_s / mean(sigma_t / combined) (spectral branch) and sigma_s / sigma_t, with sigma_s = sigma_t * albedo, combined = sigma_t.
+__global__ void k_medium_prepare(DMedium *media, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    DMedium &M = media[i];
+    const V3 st(M.sigma_t[0], M.sigma_t[1], M.sigma_t[2]), ss = st * V3(M.albedo[0], M.albedo[1], M.albedo[2]);
+    const V3 ws = ss / mean3(st / st), wp = ss / st;
+    M.w_spec[0] = ws.x; M.w_spec[1] = ws.y; M.w_spec[2] = ws.z; M.w_plain[0] = wp.x; M.w_plain[1] = wp.y; M.w_plain[2] = wp.z;
+}
+
 static void upload_media(DeviceScene *D, const lrt_scene_desc &d) {
     D->h_bio.assign(std::max<uint32_t>(d.n_media, 1), DBioMedium{});
     for (uint32_t i = 0; i < d.n_media; ++i) {
@@ -203,6 +214,8 @@ static void upload_media(DeviceScene *D, const lrt_scene_desc &d) {
     }
     HIP_CHECK(hipMemcpyAsync(D->d_het, D->h_het.data(), D->h_het.size() * sizeof(DHetMedium), hipMemcpyHostToDevice, D->stream));
     HIP_CHECK(hipMemcpyAsync(D->d_media, D->h_media.data(), D->h_media.size() * sizeof(DMedium), hipMemcpyHostToDevice, D->stream));
+    k_medium_prepare<<<1, 64, 0, D->stream>>>(D->d_media, (uint32_t) std::min<size_t>(D->h_media.size(), 64));
+    HIP_CHECK(hipGetLastError());
 }
 
 DeviceScene *device_scene_create(const lrt_scene_desc &d, int device) {

@@ -29,6 +29,8 @@ struct DMedium {
     float sigma_t[3]; float albedo[3];   // sigma_t already multiplied by scale
     int32_t has_spectral_extinction, sample_emitters, phase; float g;
     float scale; int32_t het;            // sigma_t = property * scale (needed by the PRB adjoint); het: heterogeneous (sc.het[index])
+    float w_spec[3], w_plain[3];         // real-scattering weights sigma_s / mean(sigma_t / combined), sigma_s / sigma_t (k_medium_prepare)
+    float pad2[2];
 };
 
 // bio media (liver / parenchyma / glissonCapsule): element coefficients of the 5-argument sample_interaction

@@ -658,6 +658,19 @@ DEV V3 emitter_eval(SceneRef sc, int e, const SI &si) {
     return (si.wi.z > 0.f) ? V3(E.radiance[0], E.radiance[1], E.radiance[2]) : V3(0.f);
 }
 
+// exp(-t * c) per channel; a medium whose channels are equal (the usual case: sigma_t = 1 * scale) pays one exponential.  The
+// values are the ones the three separate calls give (the same operation on the same operands).
+DEV V3 exp_neg(float t, V3 c) {
+    const float ex = m_exp(-t * c.x);
+    if (c.y == c.x && c.z == c.x) return V3(ex);
+    return V3(ex, m_exp(-t * c.y), m_exp(-t * c.z));
+}
+DEV V3 div_uniform(V3 a, float b) {              // a / b with one correctly rounded division when the channels of a are equal
+    const float q = a.x / b;
+    if (a.y == a.x && a.z == a.x) return V3(q);
+    return V3(q, a.y / b, a.z / b);
+}
+
 DEV float mis_weight(float a, float b) { a *= a; b *= b; float w = a / (a + b); return finite_(w) ? w : 0.f; }
 
 // ----------------------------------------------------------------- media

@@ -304,10 +304,10 @@ DEV V3 volpath_sample_emitter(SceneRef sc, SMP &rng, V3 ref_p, V3 ref_n, bool re
             bool spectral = M.has_spectral_extinction;
             if (spectral) {
                 float t = fmin_(remaining_dist, fmin_(mei.t, si.t)) - mei.mint;
-                V3 tr(m_exp(-t * mei.combined.x), m_exp(-t * mei.combined.y), m_exp(-t * mei.combined.z));
+                V3 tr = exp_neg(t, mei.combined);
                 V3 ffp = (si.t < mei.t || mei.t > remaining_dist) ? tr : tr * mei.combined;
                 float tr_pdf = idx3(ffp, channel);
-                transmittance = transmittance * ((tr_pdf > 0.f) ? tr / tr_pdf : V3(0.f));
+                transmittance = transmittance * ((tr_pdf > 0.f) ? div_uniform(tr, tr_pdf) : V3(0.f));
             }
             if ((mei.t > remaining_dist) && mei.valid()) total_dist = ds.dist;
             if (mei.t > remaining_dist) mei.t = kInf;
@@ -389,10 +389,10 @@ DEV bool volpath_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, const 
         if (si.t < mei.t) mei.t = kInf;
         if (M.has_spectral_extinction) {
             float t = fmin_(mei.t, si.t) - mei.mint;
-            V3 tr(m_exp(-t * mei.combined.x), m_exp(-t * mei.combined.y), m_exp(-t * mei.combined.z));
+            V3 tr = exp_neg(t, mei.combined);
             V3 pdf = (si.t < mei.t) ? tr : tr * mei.combined;
             float tr_pdf = idx3(pdf, channel);
-            throughput = throughput * ((tr_pdf > 0.f) ? tr / tr_pdf : V3(0.f));
+            throughput = throughput * ((tr_pdf > 0.f) ? div_uniform(tr, tr_pdf) : V3(0.f));
         }
         escaped_medium = !mei.valid();
         active_medium = mei.valid();
@@ -414,8 +414,11 @@ DEV bool volpath_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, const 
     if (!act_medium_scatter) rng.skip(3);                               // volpath.cpp:407 (NEE), 288, 289
     if (act_medium_scatter) {
         const DMedium M = sc.media[medium];
-        if (M.has_spectral_extinction) throughput = throughput * (mei.sigma_s / mean3(mei.sigma_t / mei.combined));
-        else throughput = throughput * (mei.sigma_s / mei.sigma_t);
+        if (HET && M.het) {
+            if (M.has_spectral_extinction) throughput = throughput * (mei.sigma_s / mean3(mei.sigma_t / mei.combined));
+            else throughput = throughput * (mei.sigma_s / mei.sigma_t);
+        } else if (M.has_spectral_extinction) throughput = throughput * V3(M.w_spec[0], M.w_spec[1], M.w_spec[2]);   // sigma_s / mean(sigma_t / combined), per-medium constant (k_medium_prepare)
+        else throughput = throughput * V3(M.w_plain[0], M.w_plain[1], M.w_plain[2]);                                 // sigma_s / sigma_t
         bool sample_emitters = M.sample_emitters != 0;
         valid_ray = true;
         specular_chain = !sample_emitters;

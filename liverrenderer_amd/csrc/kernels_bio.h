@@ -105,10 +105,10 @@ DEV V3 bio_sample_emitter(SceneRef sc, SMP &rng, V3 ref_p, V3 ref_n, uint32_t re
             needs_intersection = false;
             if (B.has_spectral_extinction) {
                 float t = fmin_(remaining_dist, fmin_(mei.t, si.t)) - 0.f;
-                V3 trm(m_exp(-t * mei.combined.x), m_exp(-t * mei.combined.y), m_exp(-t * mei.combined.z));
+                V3 trm = exp_neg(t, mei.combined);
                 V3 ffp = (si.t < mei.t || mei.t > remaining_dist) ? trm : trm * mei.combined;
                 float tr_pdf = idx3(ffp, channel);
-                transmittance = transmittance * ((tr_pdf > 0.f) ? trm / tr_pdf : V3(0.f));
+                transmittance = transmittance * ((tr_pdf > 0.f) ? div_uniform(trm, tr_pdf) : V3(0.f));
             }
             if ((mei.t > remaining_dist) && mei.valid()) total_dist = ds.dist;
             if (mei.t > remaining_dist) mei.t = kInf;
@@ -183,10 +183,10 @@ DEV bool biovolpath_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, con
         if (si.t < mei.t) mei.t = kInf;
         if (B.has_spectral_extinction) {                                // Medium::transmittance_eval_pdf (medium.cpp:92-104)
             float t = fmin_(mei.t, si.t) - 0.f;
-            V3 trm(m_exp(-t * mei.combined.x), m_exp(-t * mei.combined.y), m_exp(-t * mei.combined.z));
+            V3 trm = exp_neg(t, mei.combined);
             V3 pdf = (si.t < mei.t) ? trm : trm * mei.combined;
             float tr_pdf = idx3(pdf, channel);
-            throughput = throughput * ((tr_pdf > 0.f) ? trm / tr_pdf : V3(0.f));
+            throughput = throughput * ((tr_pdf > 0.f) ? div_uniform(trm, tr_pdf) : V3(0.f));
         }
         escaped_medium = !mei.valid();
         active_medium = mei.valid();
@@ -363,6 +363,9 @@ DEV bool biovolpath06_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, c
         else throughput = throughput / q;
     }
     if (!(depth <= max_depth)) alive = false;                           // `while (depth <= m_max_depth)`
+    // exact shortcut: an absorbed path (throughput exactly 0) can add nothing any more; the source keeps scattering it until the
+    // roulette catches it.  Retired now unless a later pass continues the lane's random-number stream (rp.pass_out).
+    if (!rp.pass_out && !any_nonzero(throughput)) alive = false;
     commit();
     return alive;
 }

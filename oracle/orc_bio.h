@@ -394,6 +394,10 @@ static void biovolpath06_sample(Ctx &C, Ray ray, int medium, V3 *out, bool *out_
             if (C.next() >= q) break;
             throughput = throughput / q;
         }
+        /* Exact shortcut (both sides, docs/BIO_TRANSPORT_SPEC.md section 4): an absorbed path (throughput exactly 0) can add nothing
+           any more; the source keeps scattering it until the roulette catches it (q = 0 once depth > rr_depth).  It is retired here
+           unless a later pass continues this lane's random-number stream. */
+        if (!C.stream_continues && !any_nonzero(throughput)) break;
     }
     *out = result; *out_valid = valid_ray;
 }

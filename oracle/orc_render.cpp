@@ -571,6 +571,7 @@ static float phase_eval(const lrt_medium_desc &M, V3 wi, V3 wo) {
 /* ------------------------------------------------------------ integrators */
 struct Ctx {
     const Scene &S; Sampler smp; int max_depth, rr_depth; bool hide_emitters;
+    bool stream_continues = false;  /* a later pass resumes this lane's PCG32 stream (multi-pass renders, independent sampler) */
     int grad_medium = 0;            /* PRB adjoint: medium whose parameters are differentiated, -1: all media into one set */
     bool bio_jit = true;            /* bio transport: JIT-variant reading (orc_bio.h); false: scalar_rgb reading */
     uint64_t n_iter = 0, n_shadow = 0, n_shadow_needed = 0;
@@ -1176,6 +1177,7 @@ static SampleOut render_lane(const Scene &S, const Opts &O, uint64_t lane, orc_s
     if (S.d.sampler_type == LRT_SAMPLER_LD) {            /* sampler.cpp:69-72,109-117: sample index = pass * spp_per_pass + lane % spp_per_pass */
         C.smp.sample_index = O.pass * O.spp + (uint32_t) (lane % O.spp); C.smp.sample_count = O.spp_total;
     } else if (carry && O.pass > 0) C.smp.rng.state = carry[lane];
+    C.stream_continues = carry != nullptr && S.d.sampler_type != LRT_SAMPLER_LD && O.pass + 1 < O.n_passes;
     uint32_t idx = (uint32_t) (lane / O.spp);
     uint32_t W = (uint32_t) F.crop_width;
     uint32_t py = idx / W, px = idx - py * W;
