@@ -200,7 +200,7 @@ def test_other_scene_files_load(mi):
 
 def test_xml_errors(mi):
     with pytest.raises(RuntimeError, match="unsupported integrator"):
-        mi.load_file(LIVER_XML, integrator="volpathmis")
+        mi.load_file(LIVER_XML, integrator="ptracer")
     with pytest.raises(RuntimeError, match="cannot open"):
         mi.load_file("/nonexistent/scene.xml")
     with pytest.raises(RuntimeError, match="undefined parameter"):
@@ -319,3 +319,57 @@ def test_scene_from_desc_validation(mi):
     for name, fn in cases.items():
         st, msg = attempt(fn)
         assert st != 0 and msg, name
+
+
+def test_loader_against_independent_python_parse(mi):
+    """The oracle is fed by the product's own scene loader, so the loader is checked here against a second, independent
+    reading of the same files (Python text parsing + numpy): OBJ vertex de-duplication in order of first appearance
+    (src/shapes/obj.cpp:151-260), v flipped (`:175`), to_world applied; look-at (include/mitsuba/core/transform.h:379-397);
+    every <float>/<rgb> of the liver medium; the envmap's transform chain."""
+    import xml.etree.ElementTree as ET
+    base = os.path.dirname(LIVER_XML)
+    sc = mi.load_file(LIVER_XML); d = sc.desc                                   # (sc owns the buffers d points into)
+    V, VT, VN, key, faces = [], [], [], {}, []
+    for line in open(os.path.join(base, "liver2.obj")):
+        t = line.split()
+        if not t: continue
+        if t[0] == "v": V.append([float(x) for x in t[1:4]])
+        elif t[0] == "vt": VT.append([float(x) for x in t[1:3]])
+        elif t[0] == "vn": VN.append([float(x) for x in t[1:4]])
+        elif t[0] == "f":
+            idx = []
+            for c in t[1:]:
+                k = tuple(int(x) if x else 0 for x in (c.split("/") + ["", ""])[:3])
+                idx.append(key.setdefault(k, len(key)))
+            faces.append(idx)
+    keys = sorted(key, key=key.get)
+    P = np.array([V[k[0] - 1] for k in keys]) + [-5, 5, -5]
+    UV = np.array([VT[k[1] - 1] for k in keys]); UV[:, 1] = 1 - UV[:, 1]
+    N = np.array([VN[k[2] - 1] for k in keys]); N /= np.linalg.norm(N, axis=1, keepdims=True)
+    assert d.n_vertices == len(keys) and d.n_faces == len(faces)
+    got = lambda ptr, w: np.ctypeslib.as_array(ptr, (d.n_vertices * w,)).reshape(-1, w)
+    assert np.abs(got(d.positions, 3) - P).max() < 4e-6 and np.abs(got(d.normals, 3) - N).max() < 3e-7
+    assert np.abs(got(d.texcoords, 2) - UV).max() < 1e-7
+    assert (np.ctypeslib.as_array(d.faces, (d.n_faces * 3,)).reshape(-1, 3) == np.array(faces)).all()
+    root = ET.parse(LIVER_XML).getroot()
+    la = root.find("sensor/transform/lookat").attrib
+    o, tg, up = (np.array([float(x) for x in la[k].split(",")]) for k in ("origin", "target", "up"))
+    fw = (tg - o) / np.linalg.norm(tg - o); left = np.cross(up, fw); left /= np.linalg.norm(left); nup = np.cross(fw, left)
+    M = np.eye(4); M[:3, 0], M[:3, 1], M[:3, 2], M[:3, 3] = left, nup, fw, o
+    assert np.allclose(np.array(d.sensor.to_world).reshape(4, 4), M, atol=1e-6)
+    assert d.sensor.fov_x == pytest.approx(45)                                   # fov_axis defaults to x
+    med = root.find("medium"); m = d.media[0]
+    fl = {e.attrib["name"]: float(e.attrib["value"]) for e in med.findall("float")}
+    rgb = {e.attrib["name"]: [float(x) for x in e.attrib["value"].split(",")] for e in med.findall("rgb")}
+    for layer in range(4):
+        for kind, arr in (("collagen", m.sigma_collagen), ("elastin", m.sigma_elastin)):
+            r, g, b = (fl[f"sigma_{kind}{layer + 1}_{c}"] for c in "RGB")
+            straight = kind == "elastin" and layer >= 2                            # liver.cpp:148-186: _B is read into g and _G into b,
+            assert list(arr[layer]) == pytest.approx([r, g, b] if straight else [r, b, g], rel=1e-7)   # except elastin layers 3-4
+    assert list(m.sigma_blood) == pytest.approx(rgb["sigma_blood"]) and list(m.sigma_bile) == pytest.approx(rgb["sigma_bile"])
+    assert list(m.sigma_lipid_water) == pytest.approx(rgb["sigma_lipid_water"]) and m.sigma_hepatocity == pytest.approx(fl["sigma_hepatocity"])
+    # envmap: translate, scale 1, rotate 180 deg about (1,1,1)/sqrt(3) -- later tags multiply from the left
+    a = np.array([0.57735] * 3); a /= np.linalg.norm(a)
+    R = 2 * np.outer(a, a) - np.eye(3)
+    E = np.eye(4); E[:3, :3] = R; E[:3, 3] = R @ np.array([-3, 3, 4])
+    assert np.allclose(np.array(d.emitters[0].to_world).reshape(4, 4), E, atol=1e-6)
