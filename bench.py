@@ -42,6 +42,8 @@ CONFIGS = {
                label="C2 cornell_box {integrator} {w}x{h} {spp} spp max_depth 8 (Gaussian filter)"),
     "c5": dict(scene=os.path.join(SCENES, "Parenchyma", "mitsuba3", "scene_temp.xml"), integrator="prbvolpath", spp=256, width=1920, height=1080,
                label="C5 Parenchyma {integrator} backward (primal + adjoint) {w}x{h} {spp} spp, ld sampler, tent filter"),
+    "c4": dict(scene=os.path.join(SCENES, "Liver-MultiMesh", "mitsuba3", "scene.xml"), integrator=None, spp=1024, width=1920, height=1080,
+               label="C4 Liver-MultiMesh {integrator} as committed (black diffuse liver1.obj under a constant emitter; ld sampler, box filter) {w}x{h} {spp} spp"),
     "parenchyma": dict(scene=os.path.join(SCENES, "Parenchyma", "mitsuba3", "scene_temp.xml"), integrator=None, spp=256, width=1920, height=1080,
                        label="Parenchyma {integrator} (file defaults: parenchyma medium, ld sampler, tent) {w}x{h} {spp} spp max_depth 12"),
 }

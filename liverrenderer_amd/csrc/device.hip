@@ -259,6 +259,9 @@ DeviceScene *device_scene_create(const lrt_scene_desc &d, int device) {
             for (size_t n = 0; n < n_nodes; ++n) {                 // mark the last slot of every leaf (trace_lds)
                 int32_t refs[4]; memcpy(refs, &bvh.nodes[16 * n + 12], 16);
                 for (int c = 0; c < 2; ++c) if (refs[c] < 0 && refs[2 + c] > 0) t[4 * ((size_t) (uint32_t) ~refs[c] + (size_t) refs[2 + c] - 1) + 3] = 1;
+                // child references as trace_lds's 16-bit work items (inner node index, or 0x8000 | first slot of the leaf)
+                uint32_t enc[2]; for (int c = 0; c < 2; ++c) enc[c] = refs[c] < 0 ? (0x8000u | (uint32_t) ~refs[c]) : (uint32_t) refs[c];
+                memcpy(blob.data() + 64 * n + 48, enc, 8);
             }
             D->lds.blob = (const uint4 *) D->track(dev_upload(blob.data(), blob.size(), st));
             D->lds.slot_prim = D->track(dev_upload(slot_prim.data(), slot_prim.size(), st));

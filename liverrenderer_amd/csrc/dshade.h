@@ -169,8 +169,7 @@ DEV Hit trace_lds(const LdsScene &L, const Ray &r, uint16_t *__restrict__ stack 
             float tmin1 = fmax_(fmax_(fmin_(bx0, bx1), fmin_(by0, by1)), fmax_(fmin_(bz0, bz1), 0.f));
             float tmax1 = fmin_(fmin_(fmax_(bx0, bx1), fmax_(by0, by1)), fmin_(fmax_(bz0, bz1), limit));
             bool h0 = tmin0 <= tmax0 * 1.000002f + 1e-30f, h1 = tmin1 <= tmax1 * 1.000002f + 1e-30f;
-            int r0 = (int) f2u(n3.x), r1 = (int) f2u(n3.y);
-            uint32_t c0 = r0 < 0 ? (0x8000u | (uint32_t) ~r0) : (uint32_t) r0, c1 = r1 < 0 ? (0x8000u | (uint32_t) ~r1) : (uint32_t) r1;
+            const uint32_t c0 = f2u(n3.x), c1 = f2u(n3.y);             // already work items (device.hip builds the LDS image)
             if (h0 && h1) {
                 bool swap = tmin1 < tmin0;
                 stack[sp * STRIDE] = (uint16_t) (swap ? c0 : c1); ++sp;

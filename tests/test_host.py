@@ -280,6 +280,9 @@ def test_round2_rejections(mi):
     sc.param_set("LiverMedium.phase_function.g", 0.0)              # ... and g = 0 is then an ordinary value
     assert sc.param_get("LiverMedium.phase_function.g", 1)[0] == 0.0
     p = mi.traverse(sc); p["LiverMedium.phase_function.g"] = 0.0; p.update()
+    # SURVEY 8f row 3 is not built (docs/SUBSURFACE_NOTES.md): a scene that asks for it fails loudly instead of rendering without it
+    with pytest.raises(RuntimeError, match="subsurface"):
+        mi.load_string('<scene version="3.0.0"><subsurface type="vaescatter" id="s"/><integrator type="path"/></scene>')
 
 
 def test_scene_from_desc_validation(mi):
