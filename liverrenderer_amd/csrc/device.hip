@@ -245,26 +245,25 @@ DeviceScene *device_scene_create(const lrt_scene_desc &d, int device) {
         int optin = 0; if (hipDeviceGetAttribute(&optin, hipDeviceAttributeSharedMemPerBlockOptin, device) != hipSuccess || optin <= 0) optin = (int) prop.sharedMemPerBlock;
         (void) hipGetLastError();
         const size_t lds_limit = std::min<size_t>((size_t) std::max(optin, 0), 160 * 1024) - 512;
-        if (d.n_faces > 0 && n_verts <= 65535 && n_nodes <= 32767 && n_slots <= 32767 && bvh.max_depth < LRT_LDS_STACK && total <= lds_limit && !getenv("LRT_NO_LDS_BVH")) {
+        if (d.n_faces > 0 && d.n_faces <= 32767 && n_verts <= 65535 && n_nodes <= 32767 && n_slots <= 32767 && bvh.max_depth < LRT_LDS_STACK && total <= lds_limit && !getenv("LRT_NO_LDS_BVH")) {
             std::vector<unsigned char> blob(nodes_b + verts_b + tris_b, 0);
             memcpy(blob.data(), bvh.nodes.data(), nodes_b);
             float *v = reinterpret_cast<float *>(blob.data() + nodes_b);
             for (size_t i = 0; i < n_verts; ++i) { v[4 * i] = d.positions[3 * i]; v[4 * i + 1] = d.positions[3 * i + 1]; v[4 * i + 2] = d.positions[3 * i + 2]; v[4 * i + 3] = 0.f; }
             uint16_t *t = reinterpret_cast<uint16_t *>(blob.data() + nodes_b + verts_b);
-            std::vector<uint32_t> slot_prim(n_slots);
-            for (size_t sl = 0; sl < n_slots; ++sl) {
-                uint32_t f; memcpy(&f, &bvh.tris[12 * sl + 3], 4); slot_prim[sl] = f;
+            for (size_t sl = 0; sl < n_slots; ++sl) {               // 4th word: face index << 1 | "last slot of its leaf"
+                uint32_t f; memcpy(&f, &bvh.tris[12 * sl + 3], 4);
                 for (int k = 0; k < 3; ++k) t[4 * sl + k] = (uint16_t) d.faces[3 * (size_t) f + k];
+                t[4 * sl + 3] = (uint16_t) (f << 1);
             }
             for (size_t n = 0; n < n_nodes; ++n) {                 // mark the last slot of every leaf (trace_lds)
                 int32_t refs[4]; memcpy(refs, &bvh.nodes[16 * n + 12], 16);
-                for (int c = 0; c < 2; ++c) if (refs[c] < 0 && refs[2 + c] > 0) t[4 * ((size_t) (uint32_t) ~refs[c] + (size_t) refs[2 + c] - 1) + 3] = 1;
+                for (int c = 0; c < 2; ++c) if (refs[c] < 0 && refs[2 + c] > 0) t[4 * ((size_t) (uint32_t) ~refs[c] + (size_t) refs[2 + c] - 1) + 3] |= 1;
                 // child references as trace_lds's 16-bit work items (inner node index, or 0x8000 | first slot of the leaf)
                 uint32_t enc[2]; for (int c = 0; c < 2; ++c) enc[c] = refs[c] < 0 ? (0x8000u | (uint32_t) ~refs[c]) : (uint32_t) refs[c];
                 memcpy(blob.data() + 64 * n + 48, enc, 8);
             }
             D->lds.blob = (const uint4 *) D->track(dev_upload(blob.data(), blob.size(), st));
-            D->lds.slot_prim = D->track(dev_upload(slot_prim.data(), slot_prim.size(), st));
             D->lds.blob_bytes = (uint32_t) blob.size(); D->lds.nodes_off = 0; D->lds.verts_off = (uint32_t) nodes_b; D->lds.tris_off = (uint32_t) (nodes_b + verts_b);
             D->lds.stack_off = (uint32_t) blob.size(); D->lds.total_bytes = (uint32_t) total;
             #define LRT_SMEM(K) HIP_CHECK(hipFuncSetAttribute((const void *) K, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_limit))

@@ -197,7 +197,7 @@ struct DCounters {             // device-resident queue / statistics words
 // LDS image of the scene for the persistent traversal kernel: [nodes | verts (float4) | tris (4 x u16)] copied verbatim
 // from `blob`, followed by the per-thread traversal stacks.
 struct DLdsInfo {
-    const uint4 *blob; const uint32_t *slot_prim;
+    const uint4 *blob;
     uint32_t blob_bytes, nodes_off, verts_off, tris_off, stack_off, total_bytes;
 };
 

@@ -12,7 +12,7 @@ namespace lrt {
 #define LRT_STACK 32
 
 struct Ray { V3 o, d; float maxt; };
-struct Hit { float t, u, v; uint32_t prim; };
+struct Hit { float t, u, v; uint32_t prim; uint32_t slot = 0xffffffffu; };   // slot: the LDS tracer's triangle slot (vertex indices without a global load), else none
 struct SI { bool valid; float t; V3 p, n; Frame sh; V2 uv; V3 dp_du, dp_dv, wi; uint32_t prim, shape; };
 
 // ------------------------------------------------------------- traversal
@@ -100,6 +100,7 @@ struct GlobalTracer {                      // BVH in global memory (any scene si
     SceneRef sc; int *stack;
     DEV Hit closest(const Ray &r) const { return trace<false>(sc, r, stack); }
     DEV Hit any(const Ray &r) const { return trace<true>(sc, r, stack); }
+    DEV SI surface(SceneRef s, const Ray &r, const Hit &h) const;
 };
 
 // Whole BVH resident in LDS (scenes whose image fits next to the traversal stacks: the liver meshes and the Cornell
@@ -107,14 +108,15 @@ struct GlobalTracer {                      // BVH in global memory (any scene si
 // entries.  Edge vectors are formed in the kernel with the same float subtractions the host builder uses, so hits
 // are bit-identical to the global-memory path.
 struct LdsScene {
-    const float4 *nodes; const float4 *verts; const uint2 *tris; const uint32_t *slot_prim /* global */;
+    const float4 *nodes; const float4 *verts; const uint2 *tris;
     uint32_t n_faces, root_is_leaf, root_first, root_count;
 };
 #define LRT_LDS_STACK 24
 #define LRT_LDS_BLOCK_MAX 1024
 
-DEV void test_tri_lds(const LdsScene &L, uint32_t slot, V3 o, V3 d, float maxt, Hit &best) {
-    uint2 ix = L.tris[slot];
+// `ix` = the slot's index words: three 16-bit vertex indices, then (face index << 1 | last-slot-of-the-leaf flag)
+// While a traversal runs, best.prim = face index | slot << 16 (both < 0x8000; 0xffffffff = no hit yet).
+DEV void test_tri_lds(const LdsScene &L, uint2 ix, uint32_t slot, V3 o, V3 d, float maxt, Hit &best) {
     float4 a = L.verts[ix.x & 0xffffu], b = L.verts[ix.x >> 16], c = L.verts[ix.y & 0xffffu];
     V3 p0(a.x, a.y, a.z), e1(b.x - a.x, b.y - a.y, b.z - a.z), e2(c.x - a.x, c.y - a.y, c.z - a.z);
     V3 pvec = cross(d, e2);
@@ -128,8 +130,8 @@ DEV void test_tri_lds(const LdsScene &L, uint32_t slot, V3 o, V3 d, float maxt, 
     float t = dot(e2, qvec) * inv_det;
     if (!(t >= 0.f && t <= maxt)) return;
     if (t > best.t) return;
-    uint32_t f = L.slot_prim[slot];
-    if (t < best.t || f < best.prim) { best.t = t; best.u = u; best.v = v; best.prim = f; }
+    uint32_t f = ix.y >> 17;
+    if (t < best.t || f < (best.prim & 0x7fffu)) { best.t = t; best.u = u; best.v = v; best.prim = f | (slot << 16); }
 }
 
 template <bool ANY_HIT, int STRIDE>
@@ -138,7 +140,8 @@ DEV Hit trace_lds(const LdsScene &L, const Ray &r, uint16_t *__restrict__ stack 
     if (L.n_faces == 0) return best;
     const V3 o = r.o, d = r.d;
     if (L.root_is_leaf) {
-        for (uint32_t i = 0; i < L.root_count; ++i) test_tri_lds(L, L.root_first + i, o, d, r.maxt, best);
+        for (uint32_t i = 0; i < L.root_count; ++i) test_tri_lds(L, L.tris[L.root_first + i], L.root_first + i, o, d, r.maxt, best);
+        if (best.prim != 0xffffffffu) { best.slot = best.prim >> 16; best.prim &= 0x7fffu; }
         return best;
     }
     // The slab arithmetic only culls (hits are decided by the Moeller-Trumbore tests and the tie rule), so it may differ
@@ -181,14 +184,16 @@ DEV Hit trace_lds(const LdsScene &L, const Ray &r, uint16_t *__restrict__ stack 
         if (cur == DONE) break;
         uint32_t slot = cur & 0x7fffu, last;
         do {
-            last = L.tris[slot].y >> 16;
-            test_tri_lds(L, slot, o, d, r.maxt, best);
+            const uint2 ix = L.tris[slot];
+            last = (ix.y >> 16) & 1u;
+            test_tri_lds(L, ix, slot, o, d, r.maxt, best);
             ++slot;
         } while (!last);
         if (ANY_HIT && best.prim != 0xffffffffu) return best;
         if (sp == 0) break;
         --sp; cur = stack[sp * STRIDE];
     }
+    if (best.prim != 0xffffffffu) { best.slot = best.prim >> 16; best.prim &= 0x7fffu; }
     return best;
 }
 
@@ -197,6 +202,7 @@ struct LdsTracer {
     const LdsScene &L; uint16_t *stack;
     DEV Hit closest(const Ray &r) const { return trace_lds<false, STRIDE>(L, r, stack); }
     DEV Hit any(const Ray &r) const { return trace_lds<true, STRIDE>(L, r, stack); }
+    DEV SI surface(SceneRef s, const Ray &r, const Hit &h) const;
 };
 
 // --------------------------------------------------- conservative distance field
@@ -237,7 +243,9 @@ DEV bool segment_proven_empty(GridRef g, V3 o, V3 d, float maxt) {
 
 // --------------------------------------------------- surface interaction
 // src/render/mesh.cpp:1489-1659 + include/mitsuba/render/interaction.h:290-300,516-536
-DEV SI compute_si(SceneRef sc, const Ray &r, const Hit &h) {
+// `L` (LDS tracer only): vertex indices and positions of the hit triangle come from the LDS image (same values as the
+// global arrays), which takes the index loads out of the dependent chain of global loads.
+DEV SI compute_si(SceneRef sc, const Ray &r, const Hit &h, const LdsScene *L = nullptr) {
     const bool valid = h.prim != 0xffffffffu;
     // every field is written through plain locals (no member addresses escape): keeps the record in VGPRs
     float t = kInf; V3 p(0.f), n(0.f), shn(0.f), shs(0.f), sht(0.f), dp_du(0.f), dp_dv(0.f), wi = -r.d;
@@ -245,10 +253,18 @@ DEV SI compute_si(SceneRef sc, const Ray &r, const Hit &h) {
     if (valid) {
         f = h.prim; shp = sc.face_shape[f];
         const DShape sd = sc.shapes[shp];
-        uint32_t i0 = sc.faces[3 * f], i1 = sc.faces[3 * f + 1], i2 = sc.faces[3 * f + 2];
-        V3 p0(sc.positions[3 * i0], sc.positions[3 * i0 + 1], sc.positions[3 * i0 + 2]);
-        V3 p1(sc.positions[3 * i1], sc.positions[3 * i1 + 1], sc.positions[3 * i1 + 2]);
-        V3 p2(sc.positions[3 * i2], sc.positions[3 * i2 + 1], sc.positions[3 * i2 + 2]);
+        uint32_t i0, i1, i2; V3 p0, p1, p2;
+        if (L && h.slot != 0xffffffffu) {
+            const uint2 ix = L->tris[h.slot];
+            i0 = ix.x & 0xffffu; i1 = ix.x >> 16; i2 = ix.y & 0xffffu;
+            const float4 a = L->verts[i0], b = L->verts[i1], c = L->verts[i2];
+            p0 = V3(a.x, a.y, a.z); p1 = V3(b.x, b.y, b.z); p2 = V3(c.x, c.y, c.z);
+        } else {
+            i0 = sc.faces[3 * f]; i1 = sc.faces[3 * f + 1]; i2 = sc.faces[3 * f + 2];
+            p0 = V3(sc.positions[3 * i0], sc.positions[3 * i0 + 1], sc.positions[3 * i0 + 2]);
+            p1 = V3(sc.positions[3 * i1], sc.positions[3 * i1 + 1], sc.positions[3 * i1 + 2]);
+            p2 = V3(sc.positions[3 * i2], sc.positions[3 * i2 + 1], sc.positions[3 * i2 + 2]);
+        }
         float b1 = h.u, b2 = h.v, b0 = 1.f - b1 - b2;
         t = h.t;
         p = V3(fma_(p0.x, b0, fma_(p1.x, b1, p2.x * b2)), fma_(p0.y, b0, fma_(p1.y, b1, p2.y * b2)), fma_(p0.z, b0, fma_(p1.z, b1, p2.z * b2)));
@@ -288,6 +304,9 @@ DEV SI compute_si(SceneRef sc, const Ray &r, const Hit &h) {
     si.dp_du = dp_du; si.dp_dv = dp_dv; si.wi = wi; si.prim = f; si.shape = shp;
     return si;
 }
+
+DEV SI GlobalTracer::surface(SceneRef s, const Ray &r, const Hit &h) const { return compute_si(s, r, h); }
+template <int STRIDE> DEV SI LdsTracer<STRIDE>::surface(SceneRef s, const Ray &r, const Hit &h) const { return compute_si(s, r, h, &L); }
 
 // include/mitsuba/render/interaction.h:140-168
 DEV V3 offset_p(V3 p, V3 n, V3 d) {

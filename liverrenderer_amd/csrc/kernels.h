@@ -296,7 +296,7 @@ DEV V3 volpath_sample_emitter(SceneRef sc, SMP &rng, V3 ref_p, V3 ref_n, bool re
                 // Exact shortcut: a real collision (sigma_n = 0) kills the sample whether or not a
                 // surface lies in front of it when every surface blocks (no null BSDF): skip the query.
                 bool elide = mei.valid() && !sc.has_null_bsdf && !het;
-                if (!elide) { n_shadow++; Hit h = tr.closest(ray); si = compute_si(sc, ray, h); }
+                if (!elide) { n_shadow++; Hit h = tr.closest(ray); si = tr.surface(sc, ray, h); }
                 else { si.valid = false; si.t = kInf; }
             }
             if (si.t < mei.t) mei.t = kInf;
@@ -322,7 +322,7 @@ DEV V3 volpath_sample_emitter(SceneRef sc, SMP &rng, V3 ref_p, V3 ref_n, bool re
             }
         }
         bool intersect = active_surface && needs_intersection;
-        if (intersect) { n_shadow++; Hit h = tr.closest(ray); si = compute_si(sc, ray, h); needs_intersection = false; }
+        if (intersect) { n_shadow++; Hit h = tr.closest(ray); si = tr.surface(sc, ray, h); needs_intersection = false; }
         active_surface = active_surface || escaped_medium;
         if (active_surface) total_dist += si.t;
         active_surface = active_surface && si.valid && !active_medium;
@@ -381,7 +381,7 @@ DEV bool volpath_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, const 
         mei = het ? het_sample_interaction(M, sc.het[medium], ray, rng.next()) : medium_sample_interaction(M, ray, rng.next(), channel);
         if (mei.valid() && !het) ray.maxt = mei.t;                              // medium->is_homogeneous() only (volpath.cpp:221)
         if (!needs_intersection) si = compute_si(sc, ray, hkeep);                // the interaction a null collision kept
-        else if (!proven_empty) { hkeep = tr.closest(ray); si = compute_si(sc, ray, hkeep); }   // else: no surface within mei.t (look-ahead of the previous trip)
+        else if (!proven_empty) { hkeep = tr.closest(ray); si = tr.surface(sc, ray, hkeep); }   // else: no surface within mei.t (look-ahead of the previous trip)
 #ifdef LRT_EXPERIMENT
         if (!proven_empty && (rp.profile & 0x10000u)) { Ray r2 = ray; r2.o.x += 1e-30f; Hit h = tr.closest(r2); if (h.t == -1.f) si.t = 0.f; }
         if (!proven_empty && (rp.profile & 0x20000u)) { Ray r2 = ray; r2.o.x += 1e-30f; Hit h; h.prim = si.valid ? si.prim : 0xffffffffu; h.t = si.t; h.u = si.uv.x; h.v = si.uv.y; SI s2 = compute_si(sc, r2, h); if (s2.t == -1.f) si.t = 0.f; }
@@ -463,7 +463,7 @@ DEV bool volpath_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, const 
     // ---- surface interactions
     active_surface = active_surface || escaped_medium;
     bool intersect = active_surface && !escaped_medium;   // medium lanes already hold si
-    if (intersect) { Hit h = tr.closest(ray); si = compute_si(sc, ray, h); }
+    if (intersect) { Hit h = tr.closest(ray); si = tr.surface(sc, ray, h); }
     if (active_surface) {
         if (rp.hide_emitters && depth == 0 && intersect) {         // volpath.cpp:304-320, integrator.cpp:96-123
             bool skip = si.valid && sc.shapes[si.shape].emitter >= 0;
@@ -712,7 +712,7 @@ k_render(ScenePtr scp, LaunchPtr lp) {
         const uint4 *src = li.blob; uint4 *dst = reinterpret_cast<uint4 *>(smem);
         for (uint32_t k = tid; k < li.blob_bytes / 16u; k += BLOCK) dst[k] = src[k];
         L.nodes = reinterpret_cast<const float4 *>(smem + li.nodes_off); L.verts = reinterpret_cast<const float4 *>(smem + li.verts_off);
-        L.tris = reinterpret_cast<const uint2 *>(smem + li.tris_off); L.slot_prim = li.slot_prim;
+        L.tris = reinterpret_cast<const uint2 *>(smem + li.tris_off);
         L.n_faces = sc.n_faces; L.root_is_leaf = (uint32_t) sc.root_is_leaf; L.root_first = sc.root_leaf_first; L.root_count = sc.root_leaf_count;
     }
     const LdsTracer<BLOCK> tr_lds{ L, reinterpret_cast<uint16_t *>(smem + li.stack_off) + tid };
@@ -977,7 +977,7 @@ k_trace_lds(ScenePtr scp, DLdsInfo li, const float *ox, const float *oy, const f
     }
     LdsScene L;
     L.nodes = reinterpret_cast<const float4 *>(smem + li.nodes_off); L.verts = reinterpret_cast<const float4 *>(smem + li.verts_off);
-    L.tris = reinterpret_cast<const uint2 *>(smem + li.tris_off); L.slot_prim = li.slot_prim;
+    L.tris = reinterpret_cast<const uint2 *>(smem + li.tris_off);
     L.n_faces = sc.n_faces; L.root_is_leaf = (uint32_t) sc.root_is_leaf; L.root_first = sc.root_leaf_first; L.root_count = sc.root_leaf_count;
     __syncthreads();
     for (uint32_t i = blockIdx.x * 1024u + tid; i < n; i += gridDim.x * 1024u) {

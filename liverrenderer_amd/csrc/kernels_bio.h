@@ -100,7 +100,7 @@ DEV V3 bio_sample_emitter(SceneRef sc, SMP &rng, V3 ref_p, V3 ref_n, uint32_t re
             const DBioMedium &B = sc.bio[medium];
             BioMI mei = bio_sample_interaction<true>(B, ray.o, ray.d, si.t, rng.next(), channel, tissue_depth);
             if (mei.valid()) ray.maxt = fmin_(mei.t, remaining_dist);
-            if (needs_intersection) { n_shadow++; Hit h = tr.closest(ray); si = compute_si(sc, ray, h); }
+            if (needs_intersection) { n_shadow++; Hit h = tr.closest(ray); si = tr.surface(sc, ray, h); }
             if (si.t < mei.t) mei.t = kInf;
             needs_intersection = false;
             if (B.has_spectral_extinction) {
@@ -122,7 +122,7 @@ DEV V3 bio_sample_emitter(SceneRef sc, SMP &rng, V3 ref_p, V3 ref_n, uint32_t re
             }
         }
         bool intersect = active_surface && needs_intersection;
-        if (intersect) { n_shadow++; Hit h = tr.closest(ray); si = compute_si(sc, ray, h); needs_intersection = false; }
+        if (intersect) { n_shadow++; Hit h = tr.closest(ray); si = tr.surface(sc, ray, h); needs_intersection = false; }
         active_surface = active_surface || escaped_medium;
         if (active_surface) total_dist += si.t;
         active_surface = active_surface && si.valid && !active_medium;
@@ -178,7 +178,7 @@ DEV bool biovolpath_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, con
         const DBioMedium &B = sc.bio[medium];
         mei = bio_sample_interaction<true>(B, ray.o, ray.d, si_t, rng.next(), channel, tissue_depth);
         if (mei.valid()) ray.maxt = mei.t;
-        if (!proven_empty) { Hit h = tr.closest(ray); si = compute_si(sc, ray, h); }   // else: no surface within mei.t, the query returns "none"
+        if (!proven_empty) { Hit h = tr.closest(ray); si = tr.surface(sc, ray, h); }   // else: no surface within mei.t, the query returns "none"
         si_t = si.t;
         if (si.t < mei.t) mei.t = kInf;
         if (B.has_spectral_extinction) {                                // Medium::transmittance_eval_pdf (medium.cpp:92-104)
@@ -223,7 +223,7 @@ DEV bool biovolpath_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, con
         if (T.z == 0.f) result.z = 0.f;
         if (medium >= 0) throughput = throughput * T;
     }
-    if (intersect) { Hit h = tr.closest(ray); si = compute_si(sc, ray, h); si_t = si.t; }
+    if (intersect) { Hit h = tr.closest(ray); si = tr.surface(sc, ray, h); si_t = si.t; }
     if (active_surface) {
         bool count_direct = (depth == 0) || specular_chain;
         int emitter = si_emitter(sc, si);
@@ -311,7 +311,7 @@ DEV bool biovolpath06_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, c
                   (null_chain ? PF_SPECULAR : 0u) | (scattered_chain ? PF_BIO_SCATTERED : 0u) | (type_emit ? PF_BIO_EMIT : 0u) |
                   (type_full ? PF_BIO_FULL : 0u) | valid_bit;
     };
-    SI si; { Hit h = tr.closest(ray); si = compute_si(sc, ray, h); }
+    SI si; { Hit h = tr.closest(ray); si = tr.surface(sc, ray, h); }
     const bool in_medium = medium >= 0;
     BioMI mei; mei.t = kInf; mei.p = V3(0.f); mei.transmittance = V3(0.f); mei.combined = V3(0.f);
     if (in_medium) mei = bio_sample_interaction<false>(sc.bio[medium], ray.o, ray.d, si.t, rng.next(), channel, tissue_depth);

@@ -86,7 +86,7 @@ DEV V3 mis_sample_emitter(SceneRef sc, SMP &rng, V3 ref_p, V3 ref_n, bool ref_is
             const DMedium M = sc.media[medium];
             MI mei = any_medium_sample(sc, medium, M, ray, rng.next(), channel);
             if (mei.valid() && !M.het) ray.maxt = fmin_(mei.t, remaining_dist);
-            if (needs_intersection) { n_shadow++; Hit h = tr.closest(ray); si = compute_si(sc, ray, h); }
+            if (needs_intersection) { n_shadow++; Hit h = tr.closest(ray); si = tr.surface(sc, ray, h); }
             if (si.t < mei.t) mei.t = kInf;
             needs_intersection = false;
             bool is_spectral = M.has_spectral_extinction != 0, not_spectral = !is_spectral;
@@ -110,7 +110,7 @@ DEV V3 mis_sample_emitter(SceneRef sc, SMP &rng, V3 ref_p, V3 ref_n, bool ref_is
             }
         }
         bool intersect = active_surface && needs_intersection;
-        if (intersect) { n_shadow++; Hit h = tr.closest(ray); si = compute_si(sc, ray, h); }
+        if (intersect) { n_shadow++; Hit h = tr.closest(ray); si = tr.surface(sc, ray, h); }
         active_surface = active_surface || escaped_medium;
         if (active_surface) total_dist += si.t;
         active_surface = active_surface && si.valid && !active_medium;
@@ -182,7 +182,7 @@ DEV bool volpathmis_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, con
         is_spectral = M.has_spectral_extinction != 0; not_spectral = !is_spectral;
         mei = any_medium_sample(sc, medium, M, ray, rng.next(), channel);
         if (mei.valid() && !M.het) ray.maxt = mei.t;
-        if (needs_intersection) { hkeep = tr.closest(ray); si = compute_si(sc, ray, hkeep); }
+        if (needs_intersection) { hkeep = tr.closest(ray); si = tr.surface(sc, ray, hkeep); }
         needs_intersection = false;
         if (si.t < mei.t) mei.t = kInf;
         if (is_spectral) {
@@ -240,7 +240,7 @@ DEV bool volpathmis_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, con
     // ---- surface interactions
     active_surface = active_surface || escaped_medium;
     const bool intersect = active_surface && needs_intersection;
-    if (intersect) { hkeep = tr.closest(ray); si = compute_si(sc, ray, hkeep); }
+    if (intersect) { hkeep = tr.closest(ray); si = tr.surface(sc, ray, hkeep); }
     if (active_surface) {
         if (rp.hide_emitters && depth == 0 && intersect) {
             bool skip = si.valid && sc.shapes[si.shape].emitter >= 0;

@@ -42,7 +42,7 @@ DEV V3 prb_sample_emitter(SceneRef sc, SMP &rng, V3 ref_p, V3 ref_n, bool ref_is
         ray.maxt = remaining_dist;
         active = active && remaining_dist > 0.f;
         needs_intersection = needs_intersection && active;
-        if (needs_intersection) { n_shadow++; Hit h = tr.closest(ray); si = compute_si(sc, ray, h); }
+        if (needs_intersection) { n_shadow++; Hit h = tr.closest(ray); si = tr.surface(sc, ray, h); }
         needs_intersection = false;
         bool active_medium = active && medium >= 0, active_surface = active && !active_medium;
         V3 tr_multiplier(1.f);
@@ -111,7 +111,7 @@ DEV bool prb_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, const TR &
         const DMedium M = sc.media[medium];
         mei = medium_sample_interaction(M, ray, rng.next(), channel);
         if (mei.valid()) ray.maxt = mei.t;
-        if (!proven_empty) { Hit h = tr.closest(ray); si = compute_si(sc, ray, h); }
+        if (!proven_empty) { Hit h = tr.closest(ray); si = tr.surface(sc, ray, h); }
         if (si.t < mei.t) mei.t = kInf;
         seg_t = fmin_(mei.t, si.t) - mei.mint;
         V3 tr(m_exp(-seg_t * mei.combined.x), m_exp(-seg_t * mei.combined.y), m_exp(-seg_t * mei.combined.z));
@@ -144,7 +144,7 @@ DEV bool prb_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, const TR &
     // ---- surface interactions
     active_surface = active_surface || escaped_medium;
     bool intersect = active_surface && !escaped_medium;
-    if (intersect) { Hit h = tr.closest(ray); si = compute_si(sc, ray, h); }
+    if (intersect) { Hit h = tr.closest(ray); si = tr.surface(sc, ray, h); }
     if (rp.hide_emitters && intersect && depth == 0 && si.valid && sc.shapes[si.shape].emitter >= 0) {
         Ray r2 = spawn_ray(si.p, si.n, ray.d);
         bool a = true; Hit h; h.prim = 0xffffffffu; h.t = kInf; h.u = h.v = 0.f;
@@ -313,7 +313,7 @@ k_render_prb(ScenePtr scp, LaunchPtr lp) {
         const uint4 *src = li.blob; uint4 *dst = reinterpret_cast<uint4 *>(smem);
         for (uint32_t k = tid; k < li.blob_bytes / 16u; k += BLOCK) dst[k] = src[k];
         L.nodes = reinterpret_cast<const float4 *>(smem + li.nodes_off); L.verts = reinterpret_cast<const float4 *>(smem + li.verts_off);
-        L.tris = reinterpret_cast<const uint2 *>(smem + li.tris_off); L.slot_prim = li.slot_prim;
+        L.tris = reinterpret_cast<const uint2 *>(smem + li.tris_off);
         L.n_faces = sc.n_faces; L.root_is_leaf = (uint32_t) sc.root_is_leaf; L.root_first = sc.root_leaf_first; L.root_count = sc.root_leaf_count;
     }
     const LdsTracer<BLOCK> tr_lds{ L, reinterpret_cast<uint16_t *>(smem + li.stack_off) + tid };
