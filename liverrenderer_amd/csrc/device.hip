@@ -234,7 +234,7 @@ DeviceScene *device_scene_create(const lrt_scene_desc &d, int device) {
     sc.nodes = (const float4 *) D->track(dev_upload(bvh.nodes.data(), bvh.nodes.size(), st));
     sc.tris = (const float4 *) D->track(dev_upload(bvh.tris.data(), bvh.tris.size(), st));
     sc.root_is_leaf = bvh.root_is_leaf; sc.root_leaf_first = bvh.root_first; sc.root_leaf_count = bvh.root_count;
-    sc.n_faces = d.n_faces; sc.n_emitters = d.n_emitters;
+    sc.n_faces = d.n_faces; sc.n_emitters = d.n_emitters; sc.one_shape = d.n_shapes == 1;
     // ---- LDS image of the acceleration structure (persistent kernel): used when it fits next to the traversal stacks
     {
         hipDeviceProp_t prop; HIP_CHECK(hipGetDeviceProperties(&prop, device)); D->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;

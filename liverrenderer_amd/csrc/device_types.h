@@ -118,7 +118,8 @@ struct DScene {
     const float *env_hier;
     uint32_t n_faces, n_emitters;
     int32_t root_is_leaf, has_null_bsdf;
-    int32_t nee_fast_reject, pad0;   // see volpath_iteration(): in-medium NEE can be rejected before sampling the emitter
+    int32_t nee_fast_reject;         // see volpath_iteration(): in-medium NEE can be rejected before sampling the emitter
+    int32_t one_shape;               // the scene has a single shape: shape / BSDF table reads are wave-uniform (tab() in dshade.h)
     uint32_t root_leaf_first, root_leaf_count;
     DCamera cam; DFilm film; DEnv env;
     DDistGrid grid;

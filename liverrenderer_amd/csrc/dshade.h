@@ -11,6 +11,18 @@ namespace lrt {
 #define LRT_BLOCK 256
 #define LRT_STACK 32
 
+// Read-only scene tables (shapes, BSDFs, media, ...): when every active lane of the wave asks for the same entry (one
+// medium, one shape: the liver scenes), the entry comes through the scalar cache (constant address space, s_load) instead
+// of one vector load per lane and dword.  The kernels never write these tables.
+template <class T> DEV T tab(const T *table, uint32_t i, bool worth_a_look = true) {
+    if (!worth_a_look) return table[i];                  // (a wave-uniform flag: scenes with many shapes skip the test)
+    const uint32_t i0 = (uint32_t) __builtin_amdgcn_readfirstlane((int) i);
+    // (scalar loads ignore EXEC: with no active lane i0 is not an index anyone vouches for, so that case takes the masked vector path)
+    if (__builtin_amdgcn_ballot_w64(true) != 0ull && __builtin_amdgcn_ballot_w64(i != i0) == 0ull)
+    { T out; __builtin_memcpy(&out, reinterpret_cast<const LRT_CONST T *>((uintptr_t) table) + i0, sizeof(T)); return out; }
+    return table[i];
+}
+
 struct Ray { V3 o, d; float maxt; };
 struct Hit { float t, u, v; uint32_t prim; uint32_t slot = 0xffffffffu; };   // slot: the LDS tracer's triangle slot (vertex indices without a global load), else none
 struct SI { bool valid; float t; V3 p, n; Frame sh; V2 uv; V3 dp_du, dp_dv, wi; uint32_t prim, shape; };
@@ -251,8 +263,8 @@ DEV SI compute_si(SceneRef sc, const Ray &r, const Hit &h, const LdsScene *L = n
     float t = kInf; V3 p(0.f), n(0.f), shn(0.f), shs(0.f), sht(0.f), dp_du(0.f), dp_dv(0.f), wi = -r.d;
     V2 uv = { 0.f, 0.f }; uint32_t f = 0xffffffffu, shp = 0xffffffffu;
     if (valid) {
-        f = h.prim; shp = sc.face_shape[f];
-        const DShape sd = sc.shapes[shp];
+        f = h.prim; shp = 0u; if (!sc.one_shape) shp = sc.face_shape[f];
+        const DShape sd = tab(sc.shapes, shp, sc.one_shape);
         uint32_t i0, i1, i2; V3 p0, p1, p2;
         if (L && h.slot != 0xffffffffu) {
             const uint2 ix = L->tris[h.slot];
@@ -462,11 +474,11 @@ DEV float leaf_pdf(const DBsdf &B, V3 wi, V3 wo) {
 }
 
 DEV BSDFSample bsdf_sample(SceneRef sc, int b, const SI &si, float s1, float s2x, float s2y) {
-    const DBsdf B = sc.bsdfs[b];
+    const DBsdf B = tab(sc.bsdfs, b, sc.one_shape);
     if (B.type == LRT_BSDF_BUMPMAP) {               // src/bsdfs/bumpmap.cpp:138-162
         Frame pf = bump_frame(sc, B, si);
         V3 pwi = pf.to_local(si.wi);
-        BSDFSample bs = leaf_sample(sc, sc.bsdfs[B.nested], si, pwi, s1, s2x, s2y);
+        BSDFSample bs = leaf_sample(sc, tab(sc.bsdfs, B.nested, sc.one_shape), si, pwi, s1, s2x, s2y);
         bool active = any_nonzero(bs.weight);
         V3 pwo = pf.to_world(bs.wo);
         active = active && (bs.wo.z * pwo.z > 0.f);
@@ -478,26 +490,26 @@ DEV BSDFSample bsdf_sample(SceneRef sc, int b, const SI &si, float s1, float s2x
     return leaf_sample(sc, B, si, si.wi, s1, s2x, s2y);
 }
 DEV V3 bsdf_eval(SceneRef sc, int b, const SI &si, V3 wo) {
-    const DBsdf B = sc.bsdfs[b];
+    const DBsdf B = tab(sc.bsdfs, b, sc.one_shape);
     if (B.type == LRT_BSDF_BUMPMAP) {               // src/bsdfs/bumpmap.cpp:164-183
         Frame pf = bump_frame(sc, B, si);
         V3 pwi = pf.to_local(si.wi), pwo = pf.to_local(wo);
         if (!(wo.z * pwo.z > 0.f)) return V3(0.f);
-        return leaf_eval(sc, sc.bsdfs[B.nested], si, pwi, pwo) * shadow_terminator(pf.n, wo);
+        return leaf_eval(sc, tab(sc.bsdfs, B.nested, sc.one_shape), si, pwi, pwo) * shadow_terminator(pf.n, wo);
     }
     return leaf_eval(sc, B, si, si.wi, wo);
 }
 DEV float bsdf_pdf(SceneRef sc, int b, const SI &si, V3 wo) {
-    const DBsdf B = sc.bsdfs[b];
+    const DBsdf B = tab(sc.bsdfs, b, sc.one_shape);
     if (B.type == LRT_BSDF_BUMPMAP) {
         Frame pf = bump_frame(sc, B, si);
         V3 pwi = pf.to_local(si.wi), pwo = pf.to_local(wo);
         if (!(wo.z * pwo.z > 0.f)) return 0.f;
-        return leaf_pdf(sc.bsdfs[B.nested], pwi, pwo);
+        return leaf_pdf(tab(sc.bsdfs, B.nested, sc.one_shape), pwi, pwo);
     }
     return leaf_pdf(B, si.wi, wo);
 }
-DEV float bsdf_null_transmission(SceneRef sc, int b) { return sc.bsdfs[b].type == LRT_BSDF_NULL ? 1.f : 0.f; }
+DEV float bsdf_null_transmission(SceneRef sc, int b) { return tab(sc.bsdfs, b, sc.one_shape).type == LRT_BSDF_NULL ? 1.f : 0.f; }
 
 // -------------------------------------------------------------- emitters
 struct DirSample { V3 p, n, d; float pdf, dist; bool delta; int emitter; };
@@ -669,7 +681,7 @@ DEV float pdf_emitter_direction(SceneRef sc, V3 ref_p, const SI &si, int emitter
     return value * pmf;
 }
 
-DEV int si_emitter(SceneRef sc, const SI &si) { return si.valid ? sc.shapes[si.shape].emitter : sc.env.emitter; }
+DEV int si_emitter(SceneRef sc, const SI &si) { return si.valid ? tab(sc.shapes, si.shape, sc.one_shape).emitter : sc.env.emitter; }
 DEV V3 emitter_eval(SceneRef sc, int e, const SI &si) {
     if (!si.valid) return emitter_eval_env(sc, -si.wi);
     const DEmitter &E = sc.emitters[e];                 // src/emitters/area.cpp eval()

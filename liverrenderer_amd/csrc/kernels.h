@@ -277,7 +277,7 @@ DEV V3 volpath_sample_emitter(SceneRef sc, SMP &rng, V3 ref_p, V3 ref_n, bool re
     if (ds.pdf == 0.f) return V3(0.f);
     Ray ray = spawn_ray_to(ref_p, ref_n, ds.p);
     float max_dist = ray.maxt;
-    if (ref_is_surface) { const DShape sd = sc.shapes[ref_shape]; if (is_medium_transition(sd)) medium = target_medium(sd, ray.d, ref_geo_n); }
+    if (ref_is_surface) { const DShape sd = tab(sc.shapes, ref_shape, sc.one_shape); if (is_medium_transition(sd)) medium = target_medium(sd, ray.d, ref_geo_n); }
     float total_dist = 0.f;
     SI si; si.valid = false; si.t = 0.f; si.shape = 0; si.p = V3(0.f); si.n = V3(0.f);
     bool needs_intersection = true, active = true;
@@ -288,9 +288,9 @@ DEV V3 volpath_sample_emitter(SceneRef sc, SMP &rng, V3 ref_p, V3 ref_n, bool re
         bool escaped_medium = false, active_medium = medium >= 0, active_surface = !active_medium;
         if (!active_medium) rng.skip(1);                                // volpath.cpp:479
         if (active_medium) {
-            const DMedium M = sc.media[medium];
+            const DMedium M = tab(sc.media, medium);
             const bool het = HET && M.het;
-            MI mei = het ? het_sample_interaction(M, sc.het[medium], ray, rng.next()) : medium_sample_interaction(M, ray, rng.next(), channel);
+            MI mei = het ? het_sample_interaction(M, tab(sc.het, medium), ray, rng.next()) : medium_sample_interaction(M, ray, rng.next(), channel);
             if (mei.valid() && !het) ray.maxt = fmin_(mei.t, remaining_dist);    // medium->is_homogeneous() only (volpath.cpp:481)
             if (needs_intersection) {
                 // Exact shortcut: a real collision (sigma_n = 0) kills the sample whether or not a
@@ -327,13 +327,13 @@ DEV V3 volpath_sample_emitter(SceneRef sc, SMP &rng, V3 ref_p, V3 ref_n, bool re
         if (active_surface) total_dist += si.t;
         active_surface = active_surface && si.valid && !active_medium;
         if (active_surface) {
-            transmittance = transmittance * bsdf_null_transmission(sc, sc.shapes[si.shape].bsdf);
+            transmittance = transmittance * bsdf_null_transmission(sc, tab(sc.shapes, si.shape, sc.one_shape).bsdf);
             ray = spawn_ray(si.p, si.n, ray.d);
         }
         ray.maxt = remaining_dist;
         needs_intersection = needs_intersection || active_surface;
         active = (active_medium || active_surface) && any_nonzero(transmittance);
-        if (active_surface) { const DShape sd = sc.shapes[si.shape]; if (is_medium_transition(sd)) medium = target_medium(sd, ray.d, si.n); }
+        if (active_surface) { const DShape sd = tab(sc.shapes, si.shape, sc.one_shape); if (is_medium_transition(sd)) medium = target_medium(sd, ray.d, si.n); }
     }
     return transmittance * emitter_val;
 }
@@ -376,9 +376,9 @@ DEV bool volpath_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, const 
     SI si; si.valid = false; si.t = kInf;
     if (!active_medium) rng.skip(2);                                    // volpath.cpp:220,239
     if (active_medium) {
-        const DMedium M = sc.media[medium];
+        const DMedium M = tab(sc.media, medium);
         const bool het = HET && M.het;
-        mei = het ? het_sample_interaction(M, sc.het[medium], ray, rng.next()) : medium_sample_interaction(M, ray, rng.next(), channel);
+        mei = het ? het_sample_interaction(M, tab(sc.het, medium), ray, rng.next()) : medium_sample_interaction(M, ray, rng.next(), channel);
         if (mei.valid() && !het) ray.maxt = mei.t;                              // medium->is_homogeneous() only (volpath.cpp:221)
         if (!needs_intersection) si = compute_si(sc, ray, hkeep);                // the interaction a null collision kept
         else if (!proven_empty) { hkeep = tr.closest(ray); si = tr.surface(sc, ray, hkeep); }   // else: no surface within mei.t (look-ahead of the previous trip)
@@ -413,7 +413,7 @@ DEV bool volpath_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, const 
     if (HET && act_null_scatter) { ray.o = mei.p; hkeep.t = si.t - mei.t; }    // :254-257 (si.t -= mei.t)
     if (!act_medium_scatter) rng.skip(3);                               // volpath.cpp:407 (NEE), 288, 289
     if (act_medium_scatter) {
-        const DMedium M = sc.media[medium];
+        const DMedium M = tab(sc.media, medium);
         if (HET && M.het) {
             if (M.has_spectral_extinction) throughput = throughput * (mei.sigma_s / mean3(mei.sigma_t / mei.combined));
             else throughput = throughput * (mei.sigma_s / mei.sigma_t);
@@ -466,13 +466,13 @@ DEV bool volpath_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, const 
     if (intersect) { Hit h = tr.closest(ray); si = tr.surface(sc, ray, h); }
     if (active_surface) {
         if (rp.hide_emitters && depth == 0 && intersect) {         // volpath.cpp:304-320, integrator.cpp:96-123
-            bool skip = si.valid && sc.shapes[si.shape].emitter >= 0;
+            bool skip = si.valid && tab(sc.shapes, si.shape, sc.one_shape).emitter >= 0;
             if (skip) {
                 Ray r2 = spawn_ray(si.p, si.n, ray.d);
                 bool a = true; Hit h; h.prim = 0xffffffffu; h.t = kInf; h.u = h.v = 0.f;
                 while (a) {
                     h = tr.closest(r2);
-                    a = h.prim != 0xffffffffu && sc.shapes[sc.face_shape[h.prim]].emitter >= 0;
+                    a = h.prim != 0xffffffffu && tab(sc.shapes, sc.face_shape[h.prim], sc.one_shape).emitter >= 0;
                     if (a) { SI s2 = compute_si(sc, r2, h); r2 = spawn_ray(s2.p, s2.n, r2.d); }
                 }
                 si = compute_si(sc, r2, h);
@@ -492,9 +492,9 @@ DEV bool volpath_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, const 
     active_surface = active_surface && si.valid;
     if (!active_surface) rng.skip(3);                                   // volpath.cpp:407 (NEE), 366, 367
     if (active_surface) {
-        const DShape sd = sc.shapes[si.shape];
+        const DShape sd = tab(sc.shapes, si.shape, sc.one_shape);
         int b = sd.bsdf;
-        int flags = sc.bsdfs[b].flags;
+        int flags = tab(sc.bsdfs, b, sc.one_shape).flags;
         bool active_e = (flags & F_SMOOTH) && (depth + 1 < max_depth);
         if (!active_e) rng.skip(1);
         if (active_e) {
@@ -526,7 +526,7 @@ DEV bool volpath_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, const 
 #ifdef LRT_EXPERIMENT
     if (active && (rp.profile & 0x40000u) && medium >= 0 && sc.grid.enabled) {
         SMP pk = rng; (void) pk.next();
-        const DMedium M = sc.media[medium];
+        const DMedium M = tab(sc.media, medium);
         Ray r2 = ray; r2.o.x += 1e-30f;
         MI m2 = medium_sample_interaction(M, r2, pk.next(), channel);
         if (m2.valid() && segment_proven_empty(sc.grid, r2.o, r2.d, m2.t) && m2.t == -1.f) nohit = PF_NOHIT;
@@ -540,7 +540,7 @@ DEV bool volpath_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, const 
         a2 = a2 && depth < max_depth;
         if (!a2) { active = false; n_extra += 1; rng = pk; }      // the retired trip's Russian-roulette draw stays consumed (multi-pass renders)
         else if (medium >= 0 && sc.grid.enabled && !(HET && act_null_scatter)) {
-            const DMedium M = sc.media[medium];
+            const DMedium M = tab(sc.media, medium);
             if (!(HET && M.het)) {                    // a heterogeneous medium does not shorten the ray: its query is always the full one
                 MI m2 = medium_sample_interaction(M, ray, pk.next(), channel);
                 if (m2.valid() && segment_proven_empty(sc.grid, ray.o, ray.d, m2.t)) nohit = PF_NOHIT;
@@ -571,14 +571,14 @@ DEV bool path_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, const TR 
     if (max_depth == 0) { commit(); return false; }
     Hit pi = tr.closest(ray);
     if (rp.hide_emitters && depth == 0) {                          // path.cpp:178-192
-        bool skip = pi.prim != 0xffffffffu && sc.shapes[sc.face_shape[pi.prim]].emitter >= 0;
+        bool skip = pi.prim != 0xffffffffu && tab(sc.shapes, sc.face_shape[pi.prim], sc.one_shape).emitter >= 0;
         if (skip) {
             SI s0 = compute_si(sc, ray, pi);
             Ray r2 = spawn_ray(s0.p, s0.n, ray.d);
             bool a = true; Hit h; h.prim = 0xffffffffu; h.t = kInf; h.u = h.v = 0.f;
             while (a) {
                 h = tr.closest(r2);
-                a = h.prim != 0xffffffffu && sc.shapes[sc.face_shape[h.prim]].emitter >= 0;
+                a = h.prim != 0xffffffffu && tab(sc.shapes, sc.face_shape[h.prim], sc.one_shape).emitter >= 0;
                 if (a) { SI s2 = compute_si(sc, r2, h); r2 = spawn_ray(s2.p, s2.n, r2.d); }
             }
             pi = h; ray = r2;
@@ -599,12 +599,12 @@ DEV bool path_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, const TR 
         // path.cpp:227-231: a JIT variant never takes the `dr::none_or<false>` exit; the rest of the trip runs with active_em =
         // false: six sampler values are drawn (:246, :266-267, :326) and valid_ray |= si.is_valid() && !Null (:305-306)
         float a0, a1; rng.next2(a0, a1); (void) rng.next(); rng.next2(a0, a1); (void) rng.next();
-        if (si.valid && !(sc.bsdfs[sc.shapes[si.shape].bsdf].flags & F_NULL)) valid_ray = true;
+        if (si.valid && !(tab(sc.bsdfs, tab(sc.shapes, si.shape, sc.one_shape).bsdf, sc.one_shape).flags & F_NULL)) valid_ray = true;
         commit(); return false;
     }
-    const DShape sd = sc.shapes[si.shape];
+    const DShape sd = tab(sc.shapes, si.shape, sc.one_shape);
     int b = sd.bsdf;
-    bool active_em = (sc.bsdfs[b].flags & F_SMOOTH) != 0;
+    bool active_em = (tab(sc.bsdfs, b, sc.one_shape).flags & F_SMOOTH) != 0;
     DirSample ds; ds.pdf = 0.f; ds.delta = false; ds.d = V3(0.f);
     V3 em_weight(0.f), wo(0.f);
     // path.cpp:246-248: ls.sampler->next_2d() carries no mask and sits in an `if (dr::any_or<true>(active_em))`, which a

@@ -86,7 +86,7 @@ DEV V3 bio_sample_emitter(SceneRef sc, SMP &rng, V3 ref_p, V3 ref_n, uint32_t re
     if (ds.pdf == 0.f) return V3(0.f);
     Ray ray = spawn_ray_to(ref_p, ref_n, ds.p);
     float max_dist = ray.maxt;
-    { const DShape sd = sc.shapes[ref_shape]; if (is_medium_transition(sd)) medium = target_medium(sd, ray.d, ref_n); }
+    { const DShape sd = tab(sc.shapes, ref_shape, sc.one_shape); if (is_medium_transition(sd)) medium = target_medium(sd, ray.d, ref_n); }
     float total_dist = 0.f;
     SI si; si.valid = false; si.t = kInf; si.shape = 0; si.p = V3(0.f); si.n = V3(0.f);
     bool needs_intersection = true, active = true;
@@ -127,13 +127,13 @@ DEV V3 bio_sample_emitter(SceneRef sc, SMP &rng, V3 ref_p, V3 ref_n, uint32_t re
         if (active_surface) total_dist += si.t;
         active_surface = active_surface && si.valid && !active_medium;
         if (active_surface) {
-            transmittance = transmittance * bsdf_null_transmission(sc, sc.shapes[si.shape].bsdf);
+            transmittance = transmittance * bsdf_null_transmission(sc, tab(sc.shapes, si.shape, sc.one_shape).bsdf);
             ray = spawn_ray(si.p, si.n, ray.d);
         }
         ray.maxt = remaining_dist;
         needs_intersection = needs_intersection || active_surface;
         active = (active_medium || active_surface) && any_nonzero(transmittance);
-        if (active_surface) { const DShape sd = sc.shapes[si.shape]; if (is_medium_transition(sd)) medium = target_medium(sd, ray.d, si.n); }
+        if (active_surface) { const DShape sd = tab(sc.shapes, si.shape, sc.one_shape); if (is_medium_transition(sd)) medium = target_medium(sd, ray.d, si.n); }
     }
     return transmittance * emitter_val;
 }
@@ -202,7 +202,7 @@ DEV bool biovolpath_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, con
     act_medium_scatter = act_medium_scatter && active;
     if (!act_medium_scatter) rng.skip(2);                               // :283, :284
     if (act_medium_scatter) {
-        const DMedium M = sc.media[medium];
+        const DMedium M = tab(sc.media, medium);
         throughput = throughput * mei.transmittance;                    // :268 / :272
         tissue_depth += __builtin_fabsf(-ray.d.z * mei.t);              // |cos_theta(-ray.d) * mei.t|
         (void) rng.next();
@@ -239,9 +239,9 @@ DEV bool biovolpath_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, con
     active_surface = active_surface && si.valid;
     if (!active_surface) rng.skip(3);                                   // :390 (NEE), :348, :349
     if (active_surface) {
-        const DShape sd = sc.shapes[si.shape];
+        const DShape sd = tab(sc.shapes, si.shape, sc.one_shape);
         int b = sd.bsdf;
-        int flags = sc.bsdfs[b].flags;
+        int flags = tab(sc.bsdfs, b, sc.one_shape).flags;
         bool active_e = (flags & F_SMOOTH) && (depth + 1 < max_depth);
         if (!active_e) rng.skip(1);
         if (active_e) {
@@ -317,7 +317,7 @@ DEV bool biovolpath06_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, c
     if (in_medium) mei = bio_sample_interaction<false>(sc.bio[medium], ray.o, ray.d, si.t, rng.next(), channel, tissue_depth);
     bool alive = true;
     if (in_medium && mei.valid()) {                                     // :185-198
-        const DMedium M = sc.media[medium];
+        const DMedium M = tab(sc.media, medium);
         throughput = throughput * mei.transmittance;
         (void) rng.next();
         float s2x, s2y; rng.next2(s2x, s2y);
@@ -339,7 +339,7 @@ DEV bool biovolpath06_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, c
             }
             commit(); return false;
         }
-        const DShape sd = sc.shapes[si.shape];
+        const DShape sd = tab(sc.shapes, si.shape, sc.one_shape);
         const int b = sd.bsdf;
         float s1 = rng.next(), s2x, s2y; rng.next2(s2x, s2y);
         const BSDFSample bs = bsdf_sample(sc, b, si, s1, s2x, s2y);

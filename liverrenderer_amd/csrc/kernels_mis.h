@@ -54,7 +54,7 @@ template <bool SMIS> DEV V3 mis_weight2(const MisW<SMIS> &A, const MisW<SMIS> &B
 }
 
 DEV MI any_medium_sample(SceneRef sc, int medium, const DMedium &M, const Ray &ray, float sample, uint32_t channel) {
-    return M.het ? het_sample_interaction(M, sc.het[medium], ray, sample) : medium_sample_interaction(M, ray, sample, channel);
+    return M.het ? het_sample_interaction(M, tab(sc.het, medium), ray, sample) : medium_sample_interaction(M, ray, sample, channel);
 }
 
 // volpathmis.cpp:449-629 sample_emitter
@@ -72,7 +72,7 @@ DEV V3 mis_sample_emitter(SceneRef sc, SMP &rng, V3 ref_p, V3 ref_n, bool ref_is
     if (!active) return emitter_val;
     Ray ray = spawn_ray_to(ref_p, ref_n, ds.p);
     float max_dist = ray.maxt;
-    if (ref_is_surface) { const DShape sd = sc.shapes[ref_shape]; if (is_medium_transition(sd)) medium = target_medium(sd, ray.d, ref_n); }
+    if (ref_is_surface) { const DShape sd = tab(sc.shapes, ref_shape, sc.one_shape); if (is_medium_transition(sd)) medium = target_medium(sd, ray.d, ref_n); }
     float total_dist = 0.f;
     SI si; si.valid = false; si.t = kInf; si.shape = 0; si.p = V3(0.f); si.n = V3(0.f);
     bool needs_intersection = true;
@@ -83,7 +83,7 @@ DEV V3 mis_sample_emitter(SceneRef sc, SMP &rng, V3 ref_p, V3 ref_n, bool ref_is
         bool escaped_medium = false, active_medium = medium >= 0, active_surface = !active_medium;
         if (!active_medium) rng.skip(1);
         if (active_medium) {
-            const DMedium M = sc.media[medium];
+            const DMedium M = tab(sc.media, medium);
             MI mei = any_medium_sample(sc, medium, M, ray, rng.next(), channel);
             if (mei.valid() && !M.het) ray.maxt = fmin_(mei.t, remaining_dist);
             if (needs_intersection) { n_shadow++; Hit h = tr.closest(ray); si = tr.surface(sc, ray, h); }
@@ -115,7 +115,7 @@ DEV V3 mis_sample_emitter(SceneRef sc, SMP &rng, V3 ref_p, V3 ref_n, bool ref_is
         if (active_surface) total_dist += si.t;
         active_surface = active_surface && si.valid && !active_medium;
         if (active_surface) {
-            V3 bv(bsdf_null_transmission(sc, sc.shapes[si.shape].bsdf));
+            V3 bv(bsdf_null_transmission(sc, tab(sc.shapes, si.shape, sc.one_shape).bsdf));
             mis_update(nee, V3(1.f), bv, channel, true); mis_update(uni, V3(1.f), bv, channel, true);
             ray = spawn_ray(si.p, si.n, ray.d);
         }
@@ -123,7 +123,7 @@ DEV V3 mis_sample_emitter(SceneRef sc, SMP &rng, V3 ref_p, V3 ref_n, bool ref_is
         needs_intersection = needs_intersection || active_surface;
         if (SMIS) active = (active_medium || active_surface) && any_nonzero(mis_weight1(uni));
         else active = (active_medium || active_surface) && (uni.w[0][0] != 0.f || uni.w[0][1] != 0.f || uni.w[0][2] != 0.f || nee.w[0][0] != 0.f || nee.w[0][1] != 0.f || nee.w[0][2] != 0.f);
-        if (active_surface) { const DShape sd = sc.shapes[si.shape]; if (is_medium_transition(sd)) medium = target_medium(sd, ray.d, si.n); }
+        if (active_surface) { const DShape sd = tab(sc.shapes, si.shape, sc.one_shape); if (is_medium_transition(sd)) medium = target_medium(sd, ray.d, si.n); }
     }
     return emitter_val;
 }
@@ -178,7 +178,7 @@ DEV bool volpathmis_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, con
     if (!needs_intersection) si = compute_si(sc, ray, hkeep);              // a null collision kept this interaction
     if (!active_medium) rng.skip(2);
     if (active_medium) {
-        const DMedium M = sc.media[medium];
+        const DMedium M = tab(sc.media, medium);
         is_spectral = M.has_spectral_extinction != 0; not_spectral = !is_spectral;
         mei = any_medium_sample(sc, medium, M, ray, rng.next(), channel);
         if (mei.valid() && !M.het) ray.maxt = mei.t;
@@ -198,7 +198,7 @@ DEV bool volpathmis_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, con
     }
     if (!active_medium) rng.skip(3);
     if (active_medium) {
-        const DMedium M = sc.media[medium];
+        const DMedium M = tab(sc.media, medium);
         const float null_scatter_prob = mean3(mei.sigma_n / mei.combined);
         act_null_scatter = rng.next() < null_scatter_prob;
         act_medium_scatter = !act_null_scatter;
@@ -243,13 +243,13 @@ DEV bool volpathmis_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, con
     if (intersect) { hkeep = tr.closest(ray); si = tr.surface(sc, ray, hkeep); }
     if (active_surface) {
         if (rp.hide_emitters && depth == 0 && intersect) {
-            bool skip = si.valid && sc.shapes[si.shape].emitter >= 0;
+            bool skip = si.valid && tab(sc.shapes, si.shape, sc.one_shape).emitter >= 0;
             if (skip) {
                 Ray r2 = spawn_ray(si.p, si.n, ray.d);
                 bool a = true; Hit h; h.prim = 0xffffffffu; h.t = kInf; h.u = h.v = 0.f;
                 while (a) {
                     h = tr.closest(r2);
-                    a = h.prim != 0xffffffffu && sc.shapes[sc.face_shape[h.prim]].emitter >= 0;
+                    a = h.prim != 0xffffffffu && tab(sc.shapes, sc.face_shape[h.prim], sc.one_shape).emitter >= 0;
                     if (a) { SI s2 = compute_si(sc, r2, h); r2 = spawn_ray(s2.p, s2.n, r2.d); }
                 }
                 si = compute_si(sc, r2, h);
@@ -269,9 +269,9 @@ DEV bool volpathmis_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, con
     active_surface = active_surface && si.valid;
     if (!active_surface) rng.skip(3);
     if (active_surface) {
-        const DShape sd = sc.shapes[si.shape];
+        const DShape sd = tab(sc.shapes, si.shape, sc.one_shape);
         int b = sd.bsdf;
-        int flags = sc.bsdfs[b].flags;
+        int flags = tab(sc.bsdfs, b, sc.one_shape).flags;
         bool active_e = (flags & F_SMOOTH) && (depth + 1 < max_depth);
         if (!active_e) rng.skip(1);
         if (active_e) {

@@ -31,7 +31,7 @@ DEV V3 prb_sample_emitter(SceneRef sc, SMP &rng, V3 ref_p, V3 ref_n, bool ref_is
     *ds_out = ds;
     bool active = ds.pdf != 0.f;
     if (!active) { emitter_val = V3(0.f); medium = -1; }
-    if (ref_is_surface) { const DShape sd = sc.shapes[ref_shape]; if (is_medium_transition(sd)) medium = target_medium(sd, ds.d, ref_geo_n); }
+    if (ref_is_surface) { const DShape sd = tab(sc.shapes, ref_shape, sc.one_shape); if (is_medium_transition(sd)) medium = target_medium(sd, ds.d, ref_geo_n); }
     Ray ray = spawn_ray_to(ref_p, ref_n, ds.p);
     float max_dist = ray.maxt, total_dist = 0.f;
     SI si; si.valid = false; si.t = 0.f; si.shape = 0; si.p = V3(0.f); si.n = V3(0.f);
@@ -50,7 +50,7 @@ DEV V3 prb_sample_emitter(SceneRef sc, SMP &rng, V3 ref_p, V3 ref_n, bool ref_is
         if (!active_medium) rng.skip(1);             // prbvolpath.py:396: the call runs for every lane in the march
         if (active_medium) {
             (void) rng.next();
-            const DMedium M = sc.media[medium];
+            const DMedium M = tab(sc.media, medium);
             float t = fmin_(remaining_dist, si.t);
             seg_t = fmin_(t, si.t) - 0.f;
             tr_multiplier = V3(m_exp(-seg_t * M.sigma_t[0]), m_exp(-seg_t * M.sigma_t[1]), m_exp(-seg_t * M.sigma_t[2]));
@@ -58,7 +58,7 @@ DEV V3 prb_sample_emitter(SceneRef sc, SMP &rng, V3 ref_p, V3 ref_n, bool ref_is
             escaped_medium = true; active_medium = false;
         }
         active_surface = (active_surface || escaped_medium) && si.valid && !active_medium;
-        if (active_surface) tr_multiplier = tr_multiplier * bsdf_null_transmission(sc, sc.shapes[si.shape].bsdf);
+        if (active_surface) tr_multiplier = tr_multiplier * bsdf_null_transmission(sc, tab(sc.shapes, si.shape, sc.one_shape).bsdf);
         if (escaped_medium && active_surface) {
             if (tr_multiplier.x > 0.f) sum.x += scale_t;
             if (tr_multiplier.y > 0.f) sum.y += scale_t;
@@ -70,7 +70,7 @@ DEV V3 prb_sample_emitter(SceneRef sc, SMP &rng, V3 ref_p, V3 ref_n, bool ref_is
         needs_intersection = needs_intersection || active_surface;
         active = active && (active_medium || active_surface) && any_nonzero(transmittance);
         if (active) total_dist += si.t;
-        if (active_surface) { const DShape sd = sc.shapes[si.shape]; if (is_medium_transition(sd)) medium = target_medium(sd, ray.d, si.n); }
+        if (active_surface) { const DShape sd = tab(sc.shapes, si.shape, sc.one_shape); if (is_medium_transition(sd)) medium = target_medium(sd, ray.d, si.n); }
     }
     *seg_sum = sum;
     return emitter_val * transmittance;
@@ -108,7 +108,7 @@ DEV bool prb_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, const TR &
     float seg_t = 0.f;
     if (!active_medium) rng.skip(1);                  // prbvolpath.py:158
     if (active_medium) {
-        const DMedium M = sc.media[medium];
+        const DMedium M = tab(sc.media, medium);
         mei = medium_sample_interaction(M, ray, rng.next(), channel);
         if (mei.valid()) ray.maxt = mei.t;
         if (!proven_empty) { Hit h = tr.closest(ray); si = tr.surface(sc, ray, h); }
@@ -129,7 +129,7 @@ DEV bool prb_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, const TR &
     throughput = throughput * weight;
     const int gm = rp.grad_medium;
     if (ADJOINT && in_medium_segment && (gm < 0 || medium == gm)) {     // prbvolpath.py:199-204
-        const DMedium M = sc.media[medium];
+        const DMedium M = tab(sc.media, medium);
         auto term = [&](float w, float l, float dl, float st, float al, float &gs, float &ga) {
             float Lo = l / fmax_(1e-8f, w);
             float dws = w * (-seg_t) + (act_medium_scatter ? w / st : 0.f);
@@ -145,12 +145,12 @@ DEV bool prb_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, const TR &
     active_surface = active_surface || escaped_medium;
     bool intersect = active_surface && !escaped_medium;
     if (intersect) { Hit h = tr.closest(ray); si = tr.surface(sc, ray, h); }
-    if (rp.hide_emitters && intersect && depth == 0 && si.valid && sc.shapes[si.shape].emitter >= 0) {
+    if (rp.hide_emitters && intersect && depth == 0 && si.valid && tab(sc.shapes, si.shape, sc.one_shape).emitter >= 0) {
         Ray r2 = spawn_ray(si.p, si.n, ray.d);
         bool a = true; Hit h; h.prim = 0xffffffffu; h.t = kInf; h.u = h.v = 0.f;
         while (a) {
             h = tr.closest(r2);
-            a = h.prim != 0xffffffffu && sc.shapes[sc.face_shape[h.prim]].emitter >= 0;
+            a = h.prim != 0xffffffffu && tab(sc.shapes, sc.face_shape[h.prim], sc.one_shape).emitter >= 0;
             if (a) { SI s2 = compute_si(sc, r2, h); r2 = spawn_ray(s2.p, s2.n, r2.d); }
         }
         si = compute_si(sc, r2, h);
@@ -168,9 +168,9 @@ DEV bool prb_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, const TR &
     }
     active_surface = active_surface && si.valid;
     // ---- emitter sampling (prbvolpath.py:267-297)
-    int b = active_surface ? sc.shapes[si.shape].bsdf : 0;
-    bool active_e_surface = active_surface && (sc.bsdfs[b].flags & F_SMOOTH) && (depth + 1 < max_depth);
-    bool sample_emitters = act_medium_scatter ? (sc.media[medium].sample_emitters != 0) : false;
+    int b = active_surface ? tab(sc.shapes, si.shape, sc.one_shape).bsdf : 0;
+    bool active_e_surface = active_surface && (tab(sc.bsdfs, b, sc.one_shape).flags & F_SMOOTH) && (depth + 1 < max_depth);
+    bool sample_emitters = act_medium_scatter ? (tab(sc.media, medium).sample_emitters != 0) : false;
     if (act_medium_scatter) specular_chain = !sample_emitters;
     bool active_e_medium = act_medium_scatter && sample_emitters;
     if (!(active_e_surface || active_e_medium)) rng.skip(1);           // prbvolpath.py:365
@@ -180,20 +180,20 @@ DEV bool prb_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, const TR &
         V3 emitted = prb_sample_emitter(sc, rng, rp_, rn, active_e_surface, active_e_surface ? si.shape : 0u, si.n, medium, channel, &ds, tr, n_shadow, &seg_sum, gm);
         V3 nee_weight; float nee_pdf;
         if (active_e_surface) { V3 wo = si.sh.to_local(ds.d); nee_weight = bsdf_eval(sc, b, si, wo); nee_pdf = bsdf_pdf(sc, b, si, wo); }
-        else { float pv = phase_eval(sc.media[medium], mei.wi, ds.d); nee_weight = V3(pv); nee_pdf = pv; }
+        else { float pv = phase_eval(tab(sc.media, medium), mei.wi, ds.d); nee_weight = V3(pv); nee_pdf = pv; }
         V3 contrib = throughput * nee_weight * mis_weight(ds.pdf, ds.delta ? 0.f : nee_pdf) * emitted;
         L = ADJOINT ? L - contrib : L + contrib;
         if (ADJOINT) {
             G.sigma_t[0] += delta_L.x * contrib.x * seg_sum.x; G.sigma_t[1] += delta_L.y * contrib.y * seg_sum.y; G.sigma_t[2] += delta_L.z * contrib.z * seg_sum.z;
-            if (active_e_medium && sc.media[medium].phase == LRT_PHASE_HG && (gm < 0 || medium == gm))
-                G.g += (delta_L.x * contrib.x + delta_L.y * contrib.y + delta_L.z * contrib.z) * hg_dlog_dg(sc.media[medium].g, dot(ds.d, mei.wi));
+            if (active_e_medium && tab(sc.media, medium).phase == LRT_PHASE_HG && (gm < 0 || medium == gm))
+                G.g += (delta_L.x * contrib.x + delta_L.y * contrib.y + delta_L.z * contrib.z) * hg_dlog_dg(tab(sc.media, medium).g, dot(ds.d, mei.wi));
         }
     }
     // ---- phase function sampling (prbvolpath.py:299-317)
     if (!act_medium_scatter) rng.skip(2);             // prbvolpath.py:294-295
     if (act_medium_scatter) {
         valid_ray = true;
-        const DMedium M = sc.media[medium];
+        const DMedium M = tab(sc.media, medium);
         (void) rng.next();
         float s2x, s2y; rng.next2(s2x, s2y);
         V3 wo; float phase_pdf; phase_sample(M, mei.wi, s2x, s2y, &wo, &phase_pdf);
@@ -212,7 +212,7 @@ DEV bool prb_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, const TR &
     // ---- BSDF sampling (prbvolpath.py:321-349)
     if (!active_surface) rng.skip(2);                 // prbvolpath.py:317-318
     if (active_surface) {
-        const DShape sd = sc.shapes[si.shape];
+        const DShape sd = tab(sc.shapes, si.shape, sc.one_shape);
         float s1 = rng.next(), s2x, s2y; rng.next2(s2x, s2y);
         const BSDFSample bs = bsdf_sample(sc, b, si, s1, s2x, s2y);
         active_surface = bs.pdf > 0.f;
@@ -238,7 +238,7 @@ DEV bool prb_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, const TR &
         float q2 = fmin_(max3(throughput) * sqr(eta), 0.99f);
         if (a2) { float u = pk.next(); a2 = (u < q2) || !(depth > (uint32_t) rp.rr_depth); }
         if (a2) {
-            const DMedium M = sc.media[medium];
+            const DMedium M = tab(sc.media, medium);
             MI m2 = medium_sample_interaction(M, ray, pk.next(), channel);
             if (m2.valid() && segment_proven_empty(sc.grid, ray.o, ray.d, m2.t)) nohit = PF_NOHIT;
         }
