@@ -305,8 +305,14 @@ DeviceScene *device_scene_create(const lrt_scene_desc &d, int device) {
     }
     // ---- geometry attributes
     sc.positions = D->track(dev_upload(d.positions, 3 * (size_t) d.n_vertices, st));
-    sc.normals = D->track(dev_upload(d.normals, 3 * (size_t) d.n_vertices, st));
-    sc.texcoords = D->track(dev_upload(d.texcoords, 2 * (size_t) d.n_vertices, st));
+    {
+        std::vector<float> va(8 * (size_t) d.n_vertices, 0.f);
+        for (size_t v = 0; v < d.n_vertices; ++v) {
+            if (d.normals) for (int a = 0; a < 3; ++a) va[8 * v + a] = d.normals[3 * v + a];
+            if (d.texcoords) for (int a = 0; a < 2; ++a) va[8 * v + 4 + a] = d.texcoords[2 * v + a];
+        }
+        sc.vattr = (const float4 *) D->track(dev_upload(va.data(), va.size(), st));
+    }
     sc.faces = D->track(dev_upload(d.faces, 3 * (size_t) d.n_faces, st));
     sc.face_shape = D->track(dev_upload(d.face_shape, d.n_faces, st));
     std::vector<DShape> shapes(d.n_shapes);

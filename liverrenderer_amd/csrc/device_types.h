@@ -110,7 +110,8 @@ struct DScene {
     const float4 *nodes;       // 4 x float4 per BVH2 node (see bvh.h)
     const float4 *tris;        // 3 x float4 per triangle slot: p0 | e1 | e2, prim id in .w of the first
     // geometry attributes
-    const float *positions, *normals, *texcoords;
+    const float *positions;
+    const float4 *vattr;       // per vertex: (n.x, n.y, n.z, 0), (u, v, 0, 0): one 16-byte and one 8-byte load instead of five dword loads
     const uint32_t *faces, *face_shape;
     const DShape *shapes; const DBsdf *bsdfs; const DTexture *textures; const DMedium *media; const DBioMedium *bio; const DHetMedium *het; const DEmitter *emitters;
     const float *tex_data;

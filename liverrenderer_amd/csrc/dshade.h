@@ -286,8 +286,9 @@ DEV SI compute_si(SceneRef sc, const Ray &r, const Hit &h, const LdsScene *L = n
         Basis bs = coordinate_system(n);
         dp_du = bs.s; dp_dv = bs.t;
         if (sd.has_texcoords) {
-            V2 uv0 = { sc.texcoords[2 * i0], sc.texcoords[2 * i0 + 1] }, uv1 = { sc.texcoords[2 * i1], sc.texcoords[2 * i1 + 1] },
-               uv2 = { sc.texcoords[2 * i2], sc.texcoords[2 * i2 + 1] };
+            const float2 t0 = *reinterpret_cast<const float2 *>(sc.vattr + 2 * (size_t) i0 + 1), t1 = *reinterpret_cast<const float2 *>(sc.vattr + 2 * (size_t) i1 + 1),
+                         t2 = *reinterpret_cast<const float2 *>(sc.vattr + 2 * (size_t) i2 + 1);
+            V2 uv0 = { t0.x, t0.y }, uv1 = { t1.x, t1.y }, uv2 = { t2.x, t2.y };
             uv = { fma_(uv2.x, b2, fma_(uv1.x, b1, uv0.x * b0)), fma_(uv2.y, b2, fma_(uv1.y, b1, uv0.y * b0)) };
             V2 duv0 = { uv1.x - uv0.x, uv1.y - uv0.y }, duv1 = { uv2.x - uv0.x, uv2.y - uv0.y };
             float det = fma_(duv0.x, duv1.y, -(duv0.y * duv1.x)), inv_det = rcp(det);
@@ -297,9 +298,8 @@ DEV SI compute_si(SceneRef sc, const Ray &r, const Hit &h, const LdsScene *L = n
             }
         }
         if (sd.has_normals) {
-            V3 n0(sc.normals[3 * i0], sc.normals[3 * i0 + 1], sc.normals[3 * i0 + 2]);
-            V3 n1(sc.normals[3 * i1], sc.normals[3 * i1 + 1], sc.normals[3 * i1 + 2]);
-            V3 n2(sc.normals[3 * i2], sc.normals[3 * i2 + 1], sc.normals[3 * i2 + 2]);
+            const float4 a0 = sc.vattr[2 * (size_t) i0], a1 = sc.vattr[2 * (size_t) i1], a2 = sc.vattr[2 * (size_t) i2];
+            V3 n0(a0.x, a0.y, a0.z), n1(a1.x, a1.y, a1.z), n2(a2.x, a2.y, a2.z);
             V3 ni(fma_(n2.x, b2, fma_(n1.x, b1, n0.x * b0)), fma_(n2.y, b2, fma_(n1.y, b1, n0.y * b0)), fma_(n2.z, b2, fma_(n1.z, b1, n0.z * b0)));
             float il = rsqrt_(squared_norm(ni));
             shn = ni * il;
