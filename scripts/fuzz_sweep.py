@@ -1,14 +1,18 @@
-"""One-off wide sweep of tests/test_fuzz_gpu.py's random scenes: python scripts/fuzz_sweep.py FIRST LAST"""
+"""One-off wide sweep of tests/test_fuzz_gpu.py's random scenes: python scripts/fuzz_sweep.py FIRST LAST [r2]
+(r2: the round-2 families: bio integrators / media, heterogeneous media, volpathmis)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import liverrenderer_amd as mi
 import orc
-from test_fuzz_gpu import random_scene_xml
+from test_fuzz_gpu import random_scene_xml, random_scene_xml_r2
+import tempfile
+R2 = len(sys.argv) > 3 and sys.argv[3] == "r2"
+TMP = tempfile.mkdtemp()
 bad = 0
 for seed in range(int(sys.argv[1]), int(sys.argv[2])):
-    xml, integ = random_scene_xml(seed)
+    xml, integ = random_scene_xml_r2(seed, TMP) if R2 else random_scene_xml(seed)
     try:
         sc = mi.load_string(xml); o = orc.OrcScene(sc)
         h, w, _ = sc.film_shape()
@@ -35,4 +39,7 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
             print(f"seed {seed} ({integ}): {int((~same).sum())} lanes differ, n_iter {st['n_iter']} vs {o.last_stats['n_iter']}, n_shadow {st['n_shadow']} vs {o.last_stats['n_shadow_needed']}", flush=True)
     except Exception as e:
         bad += 1; print(f"seed {seed}: {type(e).__name__}: {e}", flush=True)
-print(f"swept {sys.argv[1]}..{sys.argv[2]}: {bad} failures", flush=True)
+    if seed % 100 == 99:
+        print(f"... {seed + 1} done, {bad} failures", flush=True)
+        for f in os.listdir(TMP): os.remove(os.path.join(TMP, f))
+print(f"swept {sys.argv[1]}..{sys.argv[2]}{' (r2)' if R2 else ''}: {bad} failures", flush=True)
