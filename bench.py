@@ -31,7 +31,7 @@ HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8
 SCENES = os.path.join(ROOT, "scenes")
 
 # bytes of one path record across the SoA streams (csrc/device_types.h); PRB carries one more float4 stream (delta_L)
-RECORD_BYTES = {"path": 88, "volpath": 88, "biovolpath": 92, "biovolpath06": 92, "prbvolpath": 104}
+RECORD_BYTES = {"path": 88, "volpath": 88, "biovolpath": 96, "biovolpath06": 96, "prbvolpath": 104}
 KERNEL_ID = {"path": 0, "volpath": 1, "biovolpath": 3, "biovolpath06": 4}
 CONFIGS = {
     "c3": dict(scene=os.path.join(SCENES, "Liver-SingleMesh", "mitsuba3", "scene.xml"), integrator="volpath", spp=512, width=1920, height=1080,

@@ -453,7 +453,7 @@ static void ensure_workspace(DeviceScene *D, uint32_t capacity) {
         HIP_CHECK(hipMalloc((void **) &q.res_flags, (size_t) capacity * 16)); D->track(q.res_flags);
         HIP_CHECK(hipMalloc((void **) &q.lp_lane, (size_t) capacity * 16)); D->track(q.lp_lane);
         HIP_CHECK(hipMalloc((void **) &q.rng, (size_t) capacity * 8)); D->track(q.rng);
-        HIP_CHECK(hipMalloc((void **) &q.tdepth, (size_t) capacity * 4)); D->track(q.tdepth);
+        HIP_CHECK(hipMalloc((void **) &q.tdepth, (size_t) capacity * 8)); D->track(q.tdepth);
         if (D->has_het || D->need_mis) { HIP_CHECK(hipMalloc((void **) &q.hit, (size_t) capacity * 16)); D->track(q.hit); }
         if (D->need_mis) for (float4 **w : { &q.w1, &q.w2, &q.w3, &q.w4 }) { HIP_CHECK(hipMalloc((void **) w, (size_t) capacity * 16)); D->track(*w); }
     };

@@ -161,14 +161,15 @@ struct DPathStreams {
     float4 *res_flags;         // result rgb, packed flags (bits)
     float4 *lp_lane;           // last scatter position, lane id (bits)
     uint2  *rng;               // PCG32 state
-    float  *tdepth;            // biovolpath / biovolpath06 only: the loop state `tissueDepth`
+    float2 *tdepth;            // biovolpath / biovolpath06 only: the loop state `tissueDepth` (sign bit: the cached competition was won by the hepatocytes), and the
+                               // free-flight distance the look-ahead already drew for the next trip (NaN: none)
     float4 *hit;               // volpath with heterogeneous media / volpathmis: the surface interaction a null collision keeps (t, u, v, prim)
     float4 *w1, *w2, *w3, *w4; // volpathmis only: with tp_pdf, the 18 floats of p_over_f and p_over_f_nee
 };
 #define LRT_STATE_BYTES 88     // bytes per path record across all streams (path / volpath)
 #define LRT_STATE_BYTES_MIS 168 // volpathmis: o, d, res, lp, rng, hit + five float4 of MIS weights
 #define LRT_STATE_BYTES_HET 104 // volpath with heterogeneous media: + the kept surface hit (float4)
-#define LRT_STATE_BYTES_BIO 92 // biovolpath*: + tissueDepth; the maxt slot carries the previous ray query's distance
+#define LRT_STATE_BYTES_BIO 96 // biovolpath*: + tissueDepth and the look-ahead's free-flight distance; the maxt slot carries the previous ray query's distance
 
 #define LRT_INTEGRATOR_VOLPATHMIS_PLAIN 102   // kernel selector: volpathmis with use_spectral_mis = false
 #define LRT_INTEGRATOR_VOLPATH_HET 101   // kernel selector (not an API value): volpath on a scene with heterogeneous media

@@ -18,6 +18,7 @@ namespace lrt {
 struct PathState {
     V3 o, d, tp, res, lp; float maxt, eta, last_pdf; uint32_t flags, lane; uint64_t rng_state;
     float tdepth, si_t;        // biovolpath / biovolpath06: `tissueDepth`, distance returned by the previous trip's ray query
+    float bio_dist; bool bio_hep;   // biovolpath: the element competition the look-ahead already ran for this trip (distance, NaN = none; hepatocytes won)
     float4 hit;                // volpath, heterogeneous media: the surface hit (t, u, v, prim) a null collision keeps (PF_HAVE_SI)
     float W[2][3][3];          // volpathmis: p_over_f, p_over_f_nee
 };
@@ -31,7 +32,7 @@ DEV void load_state(const QS &q, size_t i, PathState &s) {
     s.o = V3(a.x, a.y, a.z); s.maxt = a.w; s.d = V3(b.x, b.y, b.z); s.eta = b.w;
     s.tp = V3(c.x, c.y, c.z); s.last_pdf = c.w; s.res = V3(d.x, d.y, d.z); s.flags = f2u(d.w);
     s.lp = V3(e.x, e.y, e.z); s.lane = f2u(e.w); s.rng_state = ((uint64_t) r.y << 32) | r.x;
-    if (MODE == 1) { s.si_t = a.w; s.maxt = kLargest; s.tdepth = q.tdepth[i]; }
+    if (MODE == 1) { s.si_t = a.w; s.maxt = kLargest; const float2 td = q.tdepth[i]; s.tdepth = __builtin_fabsf(td.x); s.bio_hep = (f2u(td.x) >> 31) != 0u; s.bio_dist = td.y; }
     if (MODE == 2 || MODE == 3) s.hit = q.hit[i];
     if (MODE == 3) {
         const float4 w1 = q.w1[i], w2 = q.w2[i], w3 = q.w3[i], w4 = q.w4[i];
@@ -52,7 +53,7 @@ DEV void store_state(const QS &q, size_t i, const PathState &s) {
     q.res_flags[i] = make_float4(s.res.x, s.res.y, s.res.z, u2f(s.flags));
     q.lp_lane[i] = make_float4(s.lp.x, s.lp.y, s.lp.z, u2f(s.lane));
     q.rng[i] = make_uint2((uint32_t) s.rng_state, (uint32_t) (s.rng_state >> 32));
-    if (MODE == 1) q.tdepth[i] = s.tdepth;
+    if (MODE == 1) q.tdepth[i] = make_float2(s.bio_hep ? -s.tdepth : s.tdepth, s.bio_dist);
     if (MODE == 2 || MODE == 3) q.hit[i] = s.hit;
 }
 
@@ -141,7 +142,7 @@ DEV PathState generate_camera_path(SceneRef sc, RpRef rp, const uint32_t *__rest
     Ray ray = camera_ray(sc, fma_(spx, sc.film.scale_x, sc.film.offset_x), fma_(spy, sc.film.scale_y, sc.film.offset_y));
     PathState s;
     s.o = ray.o; s.d = ray.d; s.maxt = ray.maxt; s.eta = 1.f; s.tp = V3(1.f); s.res = V3(0.f); s.lp = V3(0.f); s.last_pdf = 1.f; s.lane = lane;
-    s.tdepth = 0.f; s.si_t = kInf; s.hit = make_float4(0.f, 0.f, 0.f, 0.f);
+    s.tdepth = 0.f; s.si_t = kInf; s.bio_dist = u2f(0x7fc00000u); s.bio_hep = false; s.hit = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int a = 0; a < 2; ++a) for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) s.W[a][i][j] = 1.f;         // volpathmis.cpp:158-159
                                                      // biovolpath.cpp:125,129: si = zeros (t = inf), tissueDepth = 0
     bool env_visible = !rp.hide_emitters && sc.env.type >= 0;

@@ -55,10 +55,8 @@ DEV void bio_compute_distance(const DBioMedium &B, uint32_t channel, float sampl
 // surface distance the integrator hands in (`Ray3f(ray, si.t)`).  JIT: parenchyma's `if / else if` chains keep their
 // first branch only (any_or<true>); liver's plain ifs and glissonCapsule's forced `active = true` read the same both ways.
 template <bool JIT>
-DEV BioMI bio_sample_interaction(const DBioMedium &B, V3 o, V3 d, float maxt, float sample, uint32_t channel, float depth) {
+DEV BioMI bio_finish_interaction(const DBioMedium &B, V3 o, V3 d, float maxt, uint32_t channel, int bio_type, float distance) {
     BioMI mei; mei.t = kInf; mei.p = V3(0.f); mei.transmittance = V3(1.f);
-    int bio_type; float distance;
-    bio_compute_distance(B, channel, sample, depth, bio_type, distance);
     const bool inside = distance > 0.f && distance < maxt;
     if (inside) { mei.t = distance; mei.p = fma3(d, distance, o); }
     bool active = true;
@@ -73,6 +71,19 @@ DEV BioMI bio_sample_interaction(const DBioMedium &B, V3 o, V3 d, float maxt, fl
     } else if (inside && active) mei.transmittance = onehot;
     mei.combined = V3(B.sigmat[0], B.sigmat[1], B.sigmat[2]);
     return mei;
+}
+template <bool JIT>
+DEV BioMI bio_sample_interaction(const DBioMedium &B, V3 o, V3 d, float maxt, float sample, uint32_t channel, float depth) {
+    int bio_type; float distance;
+    bio_compute_distance(B, channel, sample, depth, bio_type, distance);
+    return bio_finish_interaction<JIT>(B, o, d, maxt, channel, bio_type, distance);
+}
+// The winner's class from what a path record keeps of a competition already run (its distance and "the hepatocytes won"):
+// the same case analysis as bio_compute_distance.
+DEV int bio_cached_type(const DBioMedium &B, float depth, bool hep) {
+    const bool layered = B.type == LRT_MEDIUM_LIVER || B.type == LRT_MEDIUM_GLISSON;
+    if ((layered && !(depth > B.layer_limit[3])) || B.type == LRT_MEDIUM_GLISSON) return BIO_ATTENUATOR;
+    return hep ? BIO_ABSORBER_AND_ATTENUATOR : BIO_ABSORBER;
 }
 
 // biovolpath.cpp:383-541 sample_emitter (surface reference points only)
@@ -176,7 +187,10 @@ DEV bool biovolpath_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, con
     if (!active_medium) rng.skip(2);                                    // :226, :244
     if (active_medium) {
         const DBioMedium &B = sc.bio[medium];
-        mei = bio_sample_interaction<true>(B, ray.o, ray.d, si_t, rng.next(), channel, tissue_depth);
+        const float sample = rng.next();
+        if (s.bio_dist == s.bio_dist)                                   // the previous trip's look-ahead ran this competition (same sample, channel, depth)
+            mei = bio_finish_interaction<true>(B, ray.o, ray.d, si_t, channel, bio_cached_type(B, tissue_depth, s.bio_hep), s.bio_dist);
+        else mei = bio_sample_interaction<true>(B, ray.o, ray.d, si_t, sample, channel, tissue_depth);
         if (mei.valid()) ray.maxt = mei.t;
         if (!proven_empty) { Hit h = tr.closest(ray); si = tr.surface(sc, ray, h); }   // else: no surface within mei.t, the query returns "none"
         si_t = si.t;
@@ -271,6 +285,7 @@ DEV bool biovolpath_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, con
     // known: when the competition places an interaction inside the surface distance and the distance field proves the
     // segment free of surfaces, the path is queued in region A and skips its ray query.
     uint32_t nohit = 0;
+    float cache_dist = u2f(0x7fc00000u); bool cache_hep = false;
     if (active) {
         SMP pk = rng;
         bool a2 = any_nonzero(throughput);
@@ -279,12 +294,15 @@ DEV bool biovolpath_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, con
         a2 = a2 && depth < max_depth;
         if (!a2) { active = false; n_extra += 1; rng = pk; result = V3(0.f); }
         else if (medium >= 0 && sc.grid.enabled) {
-            const BioMI m2 = bio_sample_interaction<true>(sc.bio[medium], ray.o, ray.d, si_t, pk.next(), channel, tissue_depth);
+            int type2; float dist2;
+            bio_compute_distance(sc.bio[medium], channel, pk.next(), tissue_depth, type2, dist2);
+            const BioMI m2 = bio_finish_interaction<true>(sc.bio[medium], ray.o, ray.d, si_t, channel, type2, dist2);
             if (m2.valid() && segment_proven_empty(sc.grid, ray.o, ray.d, m2.t)) nohit = PF_NOHIT;
+            cache_dist = dist2 == dist2 ? dist2 : kInf; cache_hep = type2 == BIO_ABSORBER_AND_ATTENUATOR;   // kept in the record: the next trip starts from it
         }
     }
     commit();
-    s.flags |= nohit;
+    s.flags |= nohit; s.bio_dist = cache_dist; s.bio_hep = cache_hep;
     return active;
 }
 
