@@ -708,12 +708,15 @@ struct MI { float t; V3 p, wi; V3 sigma_s, sigma_n, sigma_t, combined; float min
             DEV bool valid() const { return t != kInf; } };
 
 // src/render/medium.cpp:40-82 + src/media/homogeneous.cpp:153-181
-DEV MI medium_sample_interaction(const DMedium &M, const Ray &ray, float sample, uint32_t channel) {
+// The free-flight distance alone (the look-ahead of volpath_iteration draws it one trip early and keeps it in the record)
+DEV float medium_sampled_t(const DMedium &M, float sample, uint32_t channel) {
+    const float mm = channel == 0 ? M.sigma_t[0] : (channel == 1 ? M.sigma_t[1] : M.sigma_t[2]);
+    return 0.f + (-m_log(1.f - sample) / mm);
+}
+DEV MI medium_interaction_at(const DMedium &M, const Ray &ray, float sampled_t) {
     MI mei; mei.wi = -ray.d;
     float mint = 0.f, maxt = fmin_(ray.maxt, kInf);
     V3 sigmat(M.sigma_t[0], M.sigma_t[1], M.sigma_t[2]);
-    float mm = idx3(sigmat, channel);
-    float sampled_t = mint + (-m_log(1.f - sample) / mm);
     bool valid = sampled_t <= maxt;
     mei.t = valid ? sampled_t : kInf;
     mei.p = fma3(ray.d, sampled_t, ray.o);
@@ -724,6 +727,9 @@ DEV MI medium_sample_interaction(const DMedium &M, const Ray &ray, float sample,
     mei.sigma_n = V3(0.f);
     mei.combined = sigmat;
     return mei;
+}
+DEV MI medium_sample_interaction(const DMedium &M, const Ray &ray, float sample, uint32_t channel) {
+    return medium_interaction_at(M, ray, medium_sampled_t(M, sample, channel));
 }
 
 // src/volumes/grid.cpp (one channel) through Dr.Jit's Texture3f::eval (trilinear, clamp): texel centres at (i + .5) / res,

@@ -18,6 +18,7 @@ namespace lrt {
 struct PathState {
     V3 o, d, tp, res, lp; float maxt, eta, last_pdf; uint32_t flags, lane; uint64_t rng_state;
     float tdepth, si_t;        // biovolpath / biovolpath06: `tissueDepth`, distance returned by the previous trip's ray query
+    float ff_t;                // volpath (homogeneous media): the free-flight distance the look-ahead already drew for this trip (NaN: none); rides in the maxt slot
     float bio_dist; bool bio_hep;   // biovolpath: the element competition the look-ahead already ran for this trip (distance, NaN = none; hepatocytes won)
     float4 hit;                // volpath, heterogeneous media: the surface hit (t, u, v, prim) a null collision keeps (PF_HAVE_SI)
     float W[2][3][3];          // volpathmis: p_over_f, p_over_f_nee
@@ -32,6 +33,7 @@ DEV void load_state(const QS &q, size_t i, PathState &s) {
     s.o = V3(a.x, a.y, a.z); s.maxt = a.w; s.d = V3(b.x, b.y, b.z); s.eta = b.w;
     s.tp = V3(c.x, c.y, c.z); s.last_pdf = c.w; s.res = V3(d.x, d.y, d.z); s.flags = f2u(d.w);
     s.lp = V3(e.x, e.y, e.z); s.lane = f2u(e.w); s.rng_state = ((uint64_t) r.y << 32) | r.x;
+    if (MODE == 0) { s.ff_t = a.w; s.maxt = kLargest; }          // a queued ray always comes from spawn_ray: maxt = largest float
     if (MODE == 1) { s.si_t = a.w; s.maxt = kLargest; const float2 td = q.tdepth[i]; s.tdepth = __builtin_fabsf(td.x); s.bio_hep = (f2u(td.x) >> 31) != 0u; s.bio_dist = td.y; }
     if (MODE == 2 || MODE == 3) s.hit = q.hit[i];
     if (MODE == 3) {
@@ -43,7 +45,7 @@ DEV void load_state(const QS &q, size_t i, PathState &s) {
 }
 template <int MODE = 0, typename QS>
 DEV void store_state(const QS &q, size_t i, const PathState &s) {
-    q.o_maxt[i] = make_float4(s.o.x, s.o.y, s.o.z, MODE == 1 ? s.si_t : s.maxt);
+    q.o_maxt[i] = make_float4(s.o.x, s.o.y, s.o.z, MODE == 1 ? s.si_t : (MODE == 0 ? s.ff_t : s.maxt));
     q.d_eta[i] = make_float4(s.d.x, s.d.y, s.d.z, s.eta);
     if (MODE == 3) {
         const float *W = &s.W[0][0][0];
@@ -142,7 +144,7 @@ DEV PathState generate_camera_path(SceneRef sc, RpRef rp, const uint32_t *__rest
     Ray ray = camera_ray(sc, fma_(spx, sc.film.scale_x, sc.film.offset_x), fma_(spy, sc.film.scale_y, sc.film.offset_y));
     PathState s;
     s.o = ray.o; s.d = ray.d; s.maxt = ray.maxt; s.eta = 1.f; s.tp = V3(1.f); s.res = V3(0.f); s.lp = V3(0.f); s.last_pdf = 1.f; s.lane = lane;
-    s.tdepth = 0.f; s.si_t = kInf; s.bio_dist = u2f(0x7fc00000u); s.bio_hep = false; s.hit = make_float4(0.f, 0.f, 0.f, 0.f);
+    s.tdepth = 0.f; s.si_t = kInf; s.ff_t = u2f(0x7fc00000u); s.bio_dist = u2f(0x7fc00000u); s.bio_hep = false; s.hit = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int a = 0; a < 2; ++a) for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) s.W[a][i][j] = 1.f;         // volpathmis.cpp:158-159
                                                      // biovolpath.cpp:125,129: si = zeros (t = inf), tissueDepth = 0
     bool env_visible = !rp.hide_emitters && sc.env.type >= 0;
@@ -379,7 +381,9 @@ DEV bool volpath_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, const 
     if (active_medium) {
         const DMedium M = tab(sc.media, medium);
         const bool het = HET && M.het;
-        mei = het ? het_sample_interaction(M, tab(sc.het, medium), ray, rng.next()) : medium_sample_interaction(M, ray, rng.next(), channel);
+        const float sample = rng.next();
+        if (!HET && s.ff_t == s.ff_t) mei = medium_interaction_at(M, ray, s.ff_t);    // the previous trip's look-ahead drew this distance (same sample, channel, medium)
+        else mei = het ? het_sample_interaction(M, tab(sc.het, medium), ray, sample) : medium_sample_interaction(M, ray, sample, channel);
         if (mei.valid() && !het) ray.maxt = mei.t;                              // medium->is_homogeneous() only (volpath.cpp:221)
         if (!needs_intersection) si = compute_si(sc, ray, hkeep);                // the interaction a null collision kept
         else if (!proven_empty) { hkeep = tr.closest(ray); si = tr.surface(sc, ray, hkeep); }   // else: no surface within mei.t (look-ahead of the previous trip)
@@ -524,6 +528,7 @@ DEV bool volpath_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, const 
     // inside a medium the next free-flight distance is known, so the distance field may already prove that the segment
     // reaches no surface: such paths are queued separately and skip the ray query.
     uint32_t nohit = 0;
+    float cache_t = u2f(0x7fc00000u);
 #ifdef LRT_EXPERIMENT
     if (active && (rp.profile & 0x40000u) && medium >= 0 && sc.grid.enabled) {
         SMP pk = rng; (void) pk.next();
@@ -543,13 +548,15 @@ DEV bool volpath_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, const 
         else if (medium >= 0 && sc.grid.enabled && !(HET && act_null_scatter)) {
             const DMedium M = tab(sc.media, medium);
             if (!(HET && M.het)) {                    // a heterogeneous medium does not shorten the ray: its query is always the full one
-                MI m2 = medium_sample_interaction(M, ray, pk.next(), channel);
+                const float t2 = medium_sampled_t(M, pk.next(), channel);
+                const MI m2 = medium_interaction_at(M, ray, t2);
                 if (m2.valid() && segment_proven_empty(sc.grid, ray.o, ray.d, m2.t)) nohit = PF_NOHIT;
+                cache_t = t2;
             }
         }
     }
     commit();
-    s.flags |= nohit;
+    s.flags |= nohit; s.ff_t = cache_t;
     if (HET && act_null_scatter && active) { s.flags |= PF_HAVE_SI; s.hit = make_float4(hkeep.t, hkeep.u, hkeep.v, u2f(hkeep.prim)); }
     return active;
 }
