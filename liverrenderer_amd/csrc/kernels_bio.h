@@ -329,10 +329,18 @@ DEV bool biovolpath06_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, c
                   (null_chain ? PF_SPECULAR : 0u) | (scattered_chain ? PF_BIO_SCATTERED : 0u) | (type_emit ? PF_BIO_EMIT : 0u) |
                   (type_full ? PF_BIO_FULL : 0u) | valid_bit;
     };
-    SI si; { Hit h = tr.closest(ray); si = tr.surface(sc, ray, h); }
+    // (look-ahead of the previous trip, below: no surface within the competition's distance -> the query's answer cannot matter)
+    const bool proven_empty = (s.flags & PF_NOHIT) != 0;
+    SI si; si.valid = false; si.t = kInf;
+    if (!proven_empty) { Hit h = tr.closest(ray); si = tr.surface(sc, ray, h); }
     const bool in_medium = medium >= 0;
     BioMI mei; mei.t = kInf; mei.p = V3(0.f); mei.transmittance = V3(0.f); mei.combined = V3(0.f);
-    if (in_medium) mei = bio_sample_interaction<false>(sc.bio[medium], ray.o, ray.d, si.t, rng.next(), channel, tissue_depth);
+    if (in_medium) {
+        const float sample = rng.next();
+        if (s.bio_dist == s.bio_dist)                                   // the competition the look-ahead already ran (same sample, channel, depth)
+            mei = bio_finish_interaction<false>(sc.bio[medium], ray.o, ray.d, si.t, channel, bio_cached_type(sc.bio[medium], tissue_depth, s.bio_hep), s.bio_dist);
+        else mei = bio_sample_interaction<false>(sc.bio[medium], ray.o, ray.d, si.t, sample, channel, tissue_depth);
+    }
     bool alive = true;
     if (in_medium && mei.valid()) {                                     // :185-198
         const DMedium M = tab(sc.media, medium);
@@ -385,6 +393,18 @@ DEV bool biovolpath06_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, c
     // roulette catches it.  Retired now unless a later pass continues the lane's random-number stream (rp.pass_out).
     if (!rp.pass_out && !any_nonzero(throughput)) alive = false;
     commit();
+    // ---- look-ahead (exact): the next trip's first draw is its free-flight sample.  The competition is run now on a copy of
+    // the generator and kept in the record; when the distance field proves that no surface lies within its distance, the
+    // next trip's interaction is inside the medium whatever the ray query would return (`distance < si.t`), and the path
+    // is queued in region A: no query at all.
+    s.bio_dist = u2f(0x7fc00000u); s.bio_hep = false;
+    if (alive && medium >= 0 && sc.grid.enabled) {
+        SMP pk = rng;
+        int type2; float dist2;
+        bio_compute_distance(sc.bio[medium], channel, pk.next(), tissue_depth, type2, dist2);
+        s.bio_dist = dist2 == dist2 ? dist2 : kInf; s.bio_hep = type2 == BIO_ABSORBER_AND_ATTENUATOR;
+        if (dist2 > 0.f && dist2 < kInf && segment_proven_empty(sc.grid, ray.o, ray.d, dist2)) s.flags |= PF_NOHIT;
+    }
     return alive;
 }
 
