@@ -5,6 +5,6 @@ python3 bench.py --steps 20 --warmup 3 > gpurun_out/r02/final/bench_c3.json 2> g
 for c in c3bio c2 c4 c5 parenchyma; do
   python3 bench.py --config $c --steps 5 --warmup 1 > gpurun_out/r02/final/bench_$c.json 2> gpurun_out/r02/final/bench_$c.err; echo "$c done: $(head -c 120 gpurun_out/r02/final/bench_$c.json)"
 done
-for c in c3 c3bio; do
-  echo "== profile $c"; scripts/r02_profile.sh r02_v8 $c > gpurun_out/r02/final/prof_$c.txt 2>&1; tail -5 gpurun_out/r02/final/prof_$c.txt
+for c in c3 c3bio parenchyma; do
+  echo "== profile $c"; scripts/r02_profile.sh r02_v11 $c > gpurun_out/r02/final/prof_$c.txt 2>&1; tail -5 gpurun_out/r02/final/prof_$c.txt
 done
