@@ -36,6 +36,18 @@ DEV float rcp(float x) { return 1.f / x; }
 DEV float rsqrt_(float x) { return 1.f / __builtin_sqrtf(x); }
 DEV float safe_sqrt(float x) { return __builtin_sqrtf(__builtin_fmaxf(x, 0.f)); }
 DEV float safe_rsqrt(float x) { return 1.f / __builtin_sqrtf(__builtin_fmaxf(x, 0.f)); }
+// Sum of `v` over the 64 lanes of the wave (every lane must be active), returned to all of them: an inclusive scan with
+// DPP row shifts (1, 2, 4, 8) and the two row broadcasts, then a read of lane 63: six v_add_f32_dpp instead of six
+// ds_bpermute round trips (lanes the EXEC mask disables and out-of-row sources read as 0: bound_ctrl, old = 0).
+template <int CTRL, int ROW_MASK> DEV float dpp_add(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, true));
+}
+DEV float wave_sum(float v) {
+    v = dpp_add<0x111, 0xf>(v); v = dpp_add<0x112, 0xf>(v); v = dpp_add<0x114, 0xf>(v); v = dpp_add<0x118, 0xf>(v);   // row_shr:1,2,4,8
+    v = dpp_add<0x142, 0xa>(v);                                                                                           // row_bcast:15 into rows 1 and 3
+    v = dpp_add<0x143, 0xc>(v);                                                                                           // row_bcast:31 into rows 2 and 3
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
 DEV float mulsign(float a, float s) { return u2f(f2u(a) ^ (f2u(s) & 0x80000000u)); }
 DEV float mulsign_neg(float a, float s) { return u2f(f2u(a) ^ (~f2u(s) & 0x80000000u)); }
 DEV float signf_(float x) { return u2f(0x3f800000u | (f2u(x) & 0x80000000u)); }

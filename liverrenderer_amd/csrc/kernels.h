@@ -256,9 +256,8 @@ DEV void finish_paths_wave(SceneRef sc, RpRef rp, float *__restrict__ film, floa
         bool mine = finishing && pixel == key;
         unsigned long long grp = __ballot(mine);
         float r = mine ? L.x : 0.f, g = mine ? L.y : 0.f, b = mine ? L.z : 0.f, al = mine ? a : 0.f, w = mine ? 1.f : 0.f;
-        for (int off = 32; off > 0; off >>= 1) {
-            r += __shfl_xor(r, off); g += __shfl_xor(g, off); b += __shfl_xor(b, off); al += __shfl_xor(al, off); w += __shfl_xor(w, off);
-        }
+        r = wave_sum(r); g = wave_sum(g); b = wave_sum(b); w = wave_sum(w);
+        if (F.has_alpha) al = wave_sum(al);
         if ((int) me == leader) {
             float *p = film + (size_t) key * F.channels;
             atomicAdd(p + 0, r); atomicAdd(p + 1, g); atomicAdd(p + 2, b);
@@ -921,10 +920,8 @@ k_splat_lanes(ScenePtr scp, LaunchPtr lp) {
             for (int xs = 0; xs < count; ++xs, ++ci) {
                 const float w = mine ? wy * rfilter_eval(F, relx + (float) xs) : 0.f;
                 float r = L.x * w, g = L.y * w, b = L.z * w, a = alpha * w, ww = w;
-                for (int off = 32; off > 0; off >>= 1) {
-                    if (!WEIGHTS_ONLY) { r += __shfl_xor(r, off); g += __shfl_xor(g, off); b += __shfl_xor(b, off); a += __shfl_xor(a, off); }
-                    ww += __shfl_xor(ww, off);
-                }
+                if (!WEIGHTS_ONLY) { r = wave_sum(r); g = wave_sum(g); b = wave_sum(b); if (F.has_alpha) a = wave_sum(a); }
+                ww = wave_sum(ww);
                 if ((int) me == (ci & 63)) { tr = r; tg = g; tb = b; ta = a; tw = ww; }
                 if ((ci & 63) == 63 || ci == n_cells - 1) {            // a chunk of (up to) 64 cells is complete: lane c flushes cell base + c
                     const int cell = (ci & ~63) + (int) me;            // (footprints wider than 8 x 8 pixels take several chunks: gaussian stddev > 0.875, tent radius > 3.5)

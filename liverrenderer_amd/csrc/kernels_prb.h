@@ -383,8 +383,7 @@ k_render_prb(ScenePtr scp, LaunchPtr lp) {
                 float g[7] = { G.sigma_t[0], G.sigma_t[1], G.sigma_t[2], G.albedo[0], G.albedo[1], G.albedo[2], G.g };
 #pragma unroll
                 for (int k = 0; k < 7; ++k) {
-                    float v = g[k];
-                    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+                    const float v = wave_sum(g[k]);
                     if (lane_in_wave == 0 && v != 0.f) atomicAdd(&s_grad[k], (double) v);
                 }
             }
