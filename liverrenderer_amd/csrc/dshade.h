@@ -237,12 +237,13 @@ DEV float dist_grid_lower_bound(GridRef g, V3 p) {
 #ifndef LRT_GRID_STEPS
 #define LRT_GRID_STEPS 3
 #endif
+template <int STEPS = LRT_GRID_STEPS>
 DEV bool segment_proven_empty(GridRef g, V3 o, V3 d, float maxt) {
     if (!g.enabled || !(maxt < 1e30f)) return false;
     float len = __builtin_amdgcn_sqrtf(dot(d, d));                       // hardware sqrt / rcp (1 ulp): inside the margins
     float remaining = maxt * len * 1.01f, inv_len = __builtin_amdgcn_rcpf(len);
     V3 p = o;
-    for (int k = 0; k < LRT_GRID_STEPS; ++k) {
+    for (int k = 0; k < STEPS; ++k) {
         float lb = dist_grid_lower_bound(g, p);
         if (remaining < lb) return true;
         if (!(lb > .5f * g.cell)) return false;

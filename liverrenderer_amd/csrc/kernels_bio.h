@@ -403,7 +403,7 @@ DEV bool biovolpath06_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, c
         int type2; float dist2;
         bio_compute_distance(sc.bio[medium], channel, pk.next(), tissue_depth, type2, dist2);
         s.bio_dist = dist2 == dist2 ? dist2 : kInf; s.bio_hep = type2 == BIO_ABSORBER_AND_ATTENUATOR;
-        if (dist2 > 0.f && dist2 < kInf && segment_proven_empty(sc.grid, ray.o, ray.d, dist2)) s.flags |= PF_NOHIT;
+        if (dist2 > 0.f && dist2 < kInf && segment_proven_empty<LRT_GRID_STEPS + 1>(sc.grid, ray.o, ray.d, dist2)) s.flags |= PF_NOHIT;   // (one more step than volpath: measured +1.8 %)
     }
     return alive;
 }
