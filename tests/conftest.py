@@ -41,3 +41,22 @@ def cornell(mi):
 @pytest.fixture(scope="session")
 def liver_small(mi):
     return mi.load_file(LIVER_XML, integrator="volpath", spp=16, res_width=128, res_height=72)
+
+
+def layer_scene_variant(name):
+    """The scene the reference's committed GlissonCapsule / Parenchyma renders were made from, rebuilt from the committed
+    scene_temp.xml: GlissonCapsule under a constant white environment (the committed file has the envmap); Parenchyma under the
+    envmap block the committed file keeps in a comment, emitters visible.  Returns (xml, base_dir)."""
+    import re
+    base = os.path.join(SCENES, name, "mitsuba3")
+    xml = open(os.path.join(base, "scene_temp.xml")).read()
+    if name == "GlissonCapsule":
+        xml, n = re.subn(r'<emitter type="envmap">.*?</emitter>', '<emitter type="constant"><rgb name="radiance" value="1.0 1.0 1.0"/></emitter>', xml, flags=re.S)
+    else:
+        env = ('<emitter type="envmap"><string name="filename" value="cavidade_latitude.exr"/><float name="scale" value="2.5"/><transform name="to_world">'
+               '<translate x="-3" y="3" z="4"/><scale value="1.0"/><rotate x="0.57735" y="0.57735" z="0.57735" angle="180"/></transform></emitter>')
+        xml, n = re.subn(r'<emitter id="Environment-constant".*?</emitter>', env, xml, flags=re.S)
+        xml, m = re.subn(r'<boolean name="hide_emitters" value="true"\s*/>', '<boolean name="hide_emitters" value="false"/>', xml)
+        assert m == 1
+    assert n == 1
+    return xml, base

@@ -5,7 +5,7 @@ and bit for bit, with equal loop-trip and shadow-ray counts.  The liver scenes l
 import numpy as np
 import pytest
 
-from conftest import LIVER_XML, PARENCHYMA_XML, GLISSON_XML, REALTIME_XML
+from conftest import LIVER_XML, PARENCHYMA_XML, GLISSON_XML, REALTIME_XML, layer_scene_variant
 from test_parity_gpu import assert_lanes_equal, center_lane, film_close
 
 pytestmark = pytest.mark.gpu
@@ -100,3 +100,20 @@ def test_bio_params_change_the_render(mi, orc):
     b = sc2.render_samples(0, 64 * 48 * 16)
     assert (a != b).any()
     assert_lanes_equal(sc2, orc.OrcScene(sc2), 0, 64 * 48 * 16)
+
+
+def test_layer_scene_reference_renders_on_the_device(mi, orc):
+    """The reference's own GlissonCapsule renders (tight) and Parenchyma renders (loose) against the HIP render: the device side
+    of tests/test_bio_oracle.py's goldens, at 256 spp."""
+    from test_bio_oracle import interior_colour, layer_golden, environment_only
+    xml, base = layer_scene_variant("GlissonCapsule")
+    env = environment_only(mi, orc, xml, base)
+    img = mi.load_string(xml, base_dir=base, spp=256, res_width=240, res_height=135, integrator="biovolpath").render().astype(np.float64)[..., :3]
+    for dev, tol in (("gpu", 0.004), ("cpu", 0.008)):                            # observed 0.05 % / 0.3 %
+        ours, ref, iou, bg = interior_colour(img, layer_golden("GlissonCapsule", dev), env)
+        assert iou > 0.99 and bg < 1e-3 and np.allclose(ours, ref, rtol=tol), (dev, ours, ref)
+    xml, base = layer_scene_variant("Parenchyma")
+    env = environment_only(mi, orc, xml, base)
+    img = mi.load_string(xml, base_dir=base, spp=256, res_width=240, res_height=135).render().astype(np.float64)[..., :3]
+    ours, ref, iou, bg = interior_colour(img, layer_golden("Parenchyma", "cpu"), env)
+    assert iou > 0.99 and bg < 1e-3 and np.allclose(ours, ref, rtol=0.2), (ours, ref)

@@ -9,7 +9,7 @@ import re
 import numpy as np
 import pytest
 
-from conftest import LIVER_XML, PARENCHYMA_XML, GLISSON_XML, ROOT
+from conftest import LIVER_XML, PARENCHYMA_XML, GLISSON_XML, ROOT, layer_scene_variant
 
 DEFAULT_STREAM = 0xda3e39cb94b95bdb
 
@@ -124,3 +124,60 @@ def test_competition_winner_statistics(mi, orc):
     p_hep = rates[3] / rates.sum()
     assert wins[0] / n == pytest.approx(p_hep, abs=4 * np.sqrt(p_hep * (1 - p_hep) / n))
     assert np.mean(dist) == pytest.approx(1 / rates.sum(), rel=0.03)
+
+
+def interior_colour(img, golden, env):
+    """(ours, reference) mean linear colour over the eroded common silhouette, silhouette IoU, mean background difference"""
+    from scipy.ndimage import binary_erosion
+    img = np.clip(img, 0, 1)
+    mg, mo = np.abs(golden - env).max(-1) > 0.05, np.abs(img - env).max(-1) > 0.05
+    inner = binary_erosion(mg & mo, iterations=6)
+    assert inner.sum() > 8000
+    return img[inner].mean(0), golden[inner].mean(0), (mg & mo).sum() / (mg | mo).sum(), np.abs(golden - img)[~(mg | mo)].mean()
+
+
+def layer_golden(name, dev):
+    return np.load(os.path.join(ROOT, "tests", "golden", f"reference_{name.lower()}_{dev}_down8.npy")).astype(np.float64)
+
+
+def environment_only(mi, orc, xml, base):
+    bg = re.sub(r'<shape type="obj".*?</shape>', '', xml, flags=re.S)
+    return np.clip(orc.OrcScene(mi.load_string(bg, base_dir=base, spp=4, res_width=240, res_height=135, integrator="path")).render().astype(np.float64)[..., :3], 0, 1)
+
+
+def test_glissoncapsule_reference_renders_weak_golden(mi, orc):
+    """The reference's committed renders of GlissonCapsule (cuda and llvm/scalar variants, 1920x1080) against the oracle's
+    `biovolpath` render of the same scene: everything inside the silhouette is transport through the `glissonCapsule`
+    medium (layers from tissueDepth, collagen / elastin competition, one-hot transmittance).  Observed at 256 spp: interior
+    colour within 0.05 % of the GPU render and 0.3 % of the CPU one per channel; `volpath` (the base-class homogeneous
+    medium) is 49 % darker, `biovolpath06` 1-8 % off.  Fixture: tests/golden/make_layer_scenes_small.py."""
+    xml, base = layer_scene_variant("GlissonCapsule")
+    env = environment_only(mi, orc, xml, base)
+    sc = mi.load_string(xml, base_dir=base, spp=64, res_width=240, res_height=135, integrator="biovolpath")
+    assert sc.desc.media[0].type == 3
+    img = orc.OrcScene(sc).render().astype(np.float64)[..., :3]
+    for dev, tol in (("gpu", 0.01), ("cpu", 0.012)):                             # 64 spp: ~0.3 % noise on the mean
+        ours, ref, iou, bg = interior_colour(img, layer_golden("GlissonCapsule", dev), env)
+        assert iou > 0.99 and bg < 1e-3
+        assert np.allclose(ours, ref, rtol=tol), (dev, ours, ref)
+    hom = orc.OrcScene(mi.load_string(xml, base_dir=base, spp=16, res_width=240, res_height=135, integrator="volpath")).render().astype(np.float64)[..., :3]
+    ours, ref, _, _ = interior_colour(hom, layer_golden("GlissonCapsule", "gpu"), env)
+    assert (ours < 0.6 * ref).all()                                              # the golden tells the bio transport from the homogeneous reading
+
+
+def test_parenchyma_reference_renders_loose_golden(mi, orc):
+    """The reference's committed renders of Parenchyma against the oracle.  They were made by another state of the medium code
+    (no reading of the committed parenchyma.cpp reproduces them tightly), so this is a loose pin: the scene's own integrator,
+    `biovolpath06` (absorbers absorb), lands within 5-12 % per channel of the CPU render (bound 20 %), while the JIT reading
+    (`biovolpath`: the `else if` branches vanish, absorbers scatter on) is 2-3 x too bright in green and blue.
+    docs/BIO_TRANSPORT_SPEC.md section 6."""
+    xml, base = layer_scene_variant("Parenchyma")
+    env = environment_only(mi, orc, xml, base)
+    g = layer_golden("Parenchyma", "cpu")
+    img = orc.OrcScene(mi.load_string(xml, base_dir=base, spp=64, res_width=240, res_height=135)).render().astype(np.float64)[..., :3]   # own default: biovolpath06
+    ours, ref, iou, bg = interior_colour(img, g, env)
+    assert iou > 0.99 and bg < 1e-3
+    assert np.allclose(ours, ref, rtol=0.2), (ours, ref)
+    jit = orc.OrcScene(mi.load_string(xml, base_dir=base, spp=16, res_width=240, res_height=135, integrator="biovolpath")).render().astype(np.float64)[..., :3]
+    ours_jit, ref, _, _ = interior_colour(jit, g, env)
+    assert (ours_jit[1:] > 2 * ref[1:]).all()
