@@ -11,6 +11,9 @@ film all-reduce when N > 1).  Default workload (`--config c3`): BASELINE config 
   --config c5           PRB adjoint d(mean image)/d(sigma_t, albedo, g) on the Parenchyma scene, 1920x1080, 256 spp
                         (a step = primal + adjoint pass; medium read as homogeneous)
   --config parenchyma   scenes/Parenchyma/mitsuba3/scene_temp.xml with its own defaults (`biovolpath06`, ld sampler, tent)
+  --config multimesh    scenes/Liver-MultiMesh/mitsuba3/scene_temp.xml with its own defaults (`biovolpath`, both meshes, both tissue
+                        media, envmap, 256 spp): the scene of BASELINE.md's published 44.6 s / 11.89 Msamples/s; `vs_baseline` is set
+  --config c4           scenes/Liver-MultiMesh/mitsuba3/scene.xml as committed (BASELINE config C4's geometry), 1024 spp
 
 For N > 1 the SAME image is sharded by 32x32 pixel tiles over the ranks (strong scaling) and the per-rank raw films are
 summed with one all-reduce before develop.  Prints ONE JSON line on rank 0 (contract: see the task statement).
@@ -44,6 +47,10 @@ CONFIGS = {
                label="C5 Parenchyma {integrator} backward (primal + adjoint) {w}x{h} {spp} spp, ld sampler, tent filter"),
     "c4": dict(scene=os.path.join(SCENES, "Liver-MultiMesh", "mitsuba3", "scene.xml"), integrator=None, spp=1024, width=1920, height=1080,
                label="C4 Liver-MultiMesh {integrator} as committed (black diffuse liver1.obj under a constant emitter; ld sampler, box filter) {w}x{h} {spp} spp"),
+    # the scene behind BASELINE.md's "Liver-MultiMesh, 256 spp, latest run: 44.638 s = 11.89 Msamples/s" (time.txt next to the file)
+    "multimesh": dict(scene=os.path.join(SCENES, "Liver-MultiMesh", "mitsuba3", "scene_temp.xml"), integrator=None, spp=256, width=1920, height=1080,
+                      published_msamples=11.89,
+                      label="Liver-MultiMesh scene_temp.xml {integrator} (file defaults: capsule shell + parenchyma mesh, glissonCapsule + parenchyma media, envmap, ld sampler, tent) {w}x{h} {spp} spp max_depth 12"),
     "parenchyma": dict(scene=os.path.join(SCENES, "Parenchyma", "mitsuba3", "scene_temp.xml"), integrator=None, spp=256, width=1920, height=1080,
                        label="Parenchyma {integrator} (file defaults: parenchyma medium, ld sampler, tent) {w}x{h} {spp} spp max_depth 12"),
 }
@@ -210,6 +217,11 @@ def main():
                       "timed_region": "lrt_render / lrt_render_backward entry to the developed image (gradients) in device memory; scene resident in HBM",
                       "parallelism": "1 GPU" if world == 1 else f"32x32 pixel tiles over {world} GPUs + RCCL film all-reduce"},
            "roofline": roofline}
+    if cfg.get("published_msamples") and world == 1 and not (a.spp or a.width or a.height or a.scene or a.integrator):
+        # BASELINE.md holds a published figure for exactly this scene, resolution and sample count (the reference's own time.txt;
+        # hardware unstated there): the ratio is reported for this config only
+        out["vs_baseline"] = round(value / cfg["published_msamples"], 2)
+        out["config"]["published"] = {"value": cfg["published_msamples"], "unit": "Msamples/s", "source": "scenes/Liver-MultiMesh/mitsuba3/time.txt (BASELINE.md), GPU unstated"}
 
     if rank == 0 and world == 1 and not backward:
         # SURVEY.md 8d's form of the metric: lrt_render entry to the developed image AND raw film in host memory (PCIe included)

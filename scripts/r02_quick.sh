@@ -4,7 +4,7 @@ TAG=${1:-q}
 O=gpurun_out/r02/$TAG
 mkdir -p $O
 python -u -m pytest tests -m gpu -q --timeout 300 -p no:cacheprovider -x > $O/tests.log 2>&1; tail -3 $O/tests.log
-for c in c3 c3bio c2 c5 parenchyma; do
+for c in c3 c3bio c2 c5 parenchyma multimesh; do
   python3 bench.py --config $c --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_$c.json 2> $O/bench_$c.err
   python3 -c "
 import json,sys

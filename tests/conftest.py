@@ -14,6 +14,7 @@ PARENCHYMA_XML = os.path.join(SCENES, "Parenchyma", "mitsuba3", "scene_temp.xml"
 GLISSON_XML = os.path.join(SCENES, "GlissonCapsule", "mitsuba3", "scene_temp.xml")
 REALTIME_XML = os.path.join(SCENES, "Liver-SingleMesh-Realtime", "mitsuba3", "scene.xml")
 MULTIMESH_XML = os.path.join(SCENES, "Liver-MultiMesh", "mitsuba3", "scene.xml")
+MULTIMESH_FULL_XML = os.path.join(SCENES, "Liver-MultiMesh", "mitsuba3", "scene_temp.xml")   # both meshes, both tissue media, envmap: what liver-multimesh.png shows
 
 
 def pytest_configure(config):

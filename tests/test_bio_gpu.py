@@ -5,7 +5,7 @@ and bit for bit, with equal loop-trip and shadow-ray counts.  The liver scenes l
 import numpy as np
 import pytest
 
-from conftest import LIVER_XML, PARENCHYMA_XML, GLISSON_XML, REALTIME_XML, layer_scene_variant
+from conftest import LIVER_XML, PARENCHYMA_XML, GLISSON_XML, REALTIME_XML, MULTIMESH_FULL_XML, ROOT, layer_scene_variant
 from test_parity_gpu import assert_lanes_equal, center_lane, film_close
 
 pytestmark = pytest.mark.gpu
@@ -117,3 +117,23 @@ def test_layer_scene_reference_renders_on_the_device(mi, orc):
     img = mi.load_string(xml, base_dir=base, spp=256, res_width=240, res_height=135).render().astype(np.float64)[..., :3]
     ours, ref, iou, bg = interior_colour(img, layer_golden("Parenchyma", "cpu"), env)
     assert iou > 0.99 and bg < 1e-3 and np.allclose(ours, ref, rtol=0.2), (ours, ref)
+
+
+def test_liver_multimesh_full_scene(mi, orc):
+    """Liver-MultiMesh/scene_temp.xml with its own defaults (biovolpath, two nested meshes, glissonCapsule + parenchyma media, ld
+    sampler, tent filter): lanes bit for bit against the oracle, and the HIP render against the reference's own render of this
+    scene (liver-multimesh.png; interior colour within 1.5 %: the fixture that decides the JIT reading of parenchyma.cpp)."""
+    import os
+    from test_bio_oracle import interior_colour, environment_only
+    sc = mi.load_file(MULTIMESH_FULL_XML, spp=16, res_width=192, res_height=108)
+    assert sc.desc.integrator.type == 3 and sc.desc.n_media == 2 and sc.desc.sampler_type == 1
+    o = orc.OrcScene(sc)
+    g = assert_lanes_equal(sc, o, 0, 192 * 108 * 16)
+    assert (g[:, :3] > 0).any(axis=1).mean() > 0.5
+    assert_lanes_equal(sc, o, center_lane(sc, 16), 1 << 14, seed=3, max_depth=40, rr_depth=2)
+    base = os.path.dirname(MULTIMESH_FULL_XML); xml = open(MULTIMESH_FULL_XML).read()
+    golden = np.load(os.path.join(ROOT, "tests", "golden", "reference_liver_multimesh_down8.npy")).astype(np.float64)
+    env = environment_only(mi, orc, xml, base)
+    img = mi.load_string(xml, base_dir=base, spp=256, res_width=240, res_height=135).render().astype(np.float64)[..., :3]
+    ours, ref, iou, bg = interior_colour(img, golden, env)
+    assert iou > 0.99 and bg < 1e-3 and np.allclose(ours, ref, rtol=0.015), (ours, ref)

@@ -9,7 +9,7 @@ import re
 import numpy as np
 import pytest
 
-from conftest import LIVER_XML, PARENCHYMA_XML, GLISSON_XML, ROOT, layer_scene_variant
+from conftest import LIVER_XML, PARENCHYMA_XML, GLISSON_XML, MULTIMESH_FULL_XML, ROOT, layer_scene_variant
 
 DEFAULT_STREAM = 0xda3e39cb94b95bdb
 
@@ -181,3 +181,25 @@ def test_parenchyma_reference_renders_loose_golden(mi, orc):
     jit = orc.OrcScene(mi.load_string(xml, base_dir=base, spp=16, res_width=240, res_height=135, integrator="biovolpath")).render().astype(np.float64)[..., :3]
     ours_jit, ref, _, _ = interior_colour(jit, g, env)
     assert (ours_jit[1:] > 2 * ref[1:]).all()
+
+
+def test_liver_multimesh_reference_render_decides_the_reading(mi, orc):
+    """The reference's committed render of the full Liver-MultiMesh scene (scene_temp.xml: Glisson's-capsule shell around the
+    parenchyma mesh, both tissue media, envmap; `biovolpath`, 256 spp; the 44.6 s / 11.9 Msamples/s entry of BASELINE.md) against
+    the oracle.  This is the one fixture in which the two readings of `parenchyma.cpp` differ inside a JIT integrator, and it
+    decides: with the JIT reading (absorbers scatter on, `else if` branches never run) the liver's interior colour agrees to
+    0.1-0.9 % per channel; the scalar reading of the medium is 22 / 71 / 74 % too dark, `biovolpath06` 17 / 52 / 57 %, the
+    homogeneous `volpath` 24 / 9 / 4 %.  Fixture: tests/golden/make_layer_scenes_small.py."""
+    base = os.path.dirname(MULTIMESH_FULL_XML); xml = open(MULTIMESH_FULL_XML).read()
+    g = np.load(os.path.join(ROOT, "tests", "golden", "reference_liver_multimesh_down8.npy")).astype(np.float64)
+    env = environment_only(mi, orc, xml, base)
+    sc = mi.load_string(xml, base_dir=base, spp=64, res_width=240, res_height=135)
+    assert sc.desc.integrator.type == 3 and sorted(sc.desc.media[i].type for i in range(sc.desc.n_media)) == [2, 3]   # biovolpath; parenchyma + glissonCapsule
+    o = orc.OrcScene(sc)
+    ours, ref, iou, bg = interior_colour(o.render().astype(np.float64)[..., :3], g, env)
+    assert iou > 0.99 and bg < 1e-3
+    assert np.allclose(ours, ref, rtol=0.025), (ours, ref)                       # 64 spp; observed 0.9 / 0.3 / 0.1 %
+    o.set_bio_reading(True)                                                      # scalar reading of the media inside biovolpath
+    ours_scalar, ref, _, _ = interior_colour(o.render(spp=16).astype(np.float64)[..., :3], g, env)
+    o.set_bio_reading(False)
+    assert (ours_scalar[1:] < 0.5 * ref[1:]).all()
