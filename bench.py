@@ -201,7 +201,9 @@ def main():
         except Exception:
             pass
     ld = scene.desc.sampler_type == 1
-    kname = ("lrt::k_render_prb<*, 1024, true, %s>" % str(ld).lower()) if backward else ("lrt::k_render<%d, 1024, true, %s>" % (KERNEL_ID[integrator], str(ld).lower()))
+    lds = bool(st.get("lds_resident", 1))                      # False: the mesh did not fit the LDS image, BVH in global memory, 256-thread workgroups
+    geom = "1024, true" if lds else "256, false"
+    kname = ("lrt::k_render_prb<*, %s, %s>" % (geom, str(ld).lower())) if backward else ("lrt::k_render<%d, %s, %s>" % (KERNEL_ID[integrator], geom, str(ld).lower()))
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "kernel": kname,
                 "launches_per_step": launches / a.steps, "avg_launch_ms": kern_ms / max(launches, 1),

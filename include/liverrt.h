@@ -220,6 +220,8 @@ typedef struct {
                                  trips retired by look-ahead move no record)        */
     double   kernel_ms;       /* sum of iteration-kernel durations (HIP events)    */
     double   total_ms;        /* whole lrt_render device time (HIP events)         */
+    uint64_t lds_resident;    /* 1: the kernels ran on the LDS-resident BVH image (1024-thread workgroups);
+                                 0: the mesh did not fit, BVH in global memory (256-thread workgroups)  [v103] */
 } lrt_render_stats;
 
 typedef struct {

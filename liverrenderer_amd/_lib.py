@@ -85,7 +85,7 @@ class RenderOpts(C.Structure):
 
 class RenderStats(C.Structure):
     _fields_ = [("n_samples", C.c_uint64), ("n_iter", C.c_uint64), ("n_shadow", C.c_uint64), ("n_launches", C.c_uint64),
-                ("n_records", C.c_uint64), ("kernel_ms", C.c_double), ("total_ms", C.c_double)]
+                ("n_records", C.c_uint64), ("kernel_ms", C.c_double), ("total_ms", C.c_double), ("lds_resident", C.c_uint64)]
 
 
 class ParamGrads(C.Structure):

@@ -28,7 +28,7 @@ static lrt_status fail(lrt_status st, const std::string &msg) { g_error = msg; r
 extern "C" {
 
 const char *lrt_last_error(void) { return g_error.c_str(); }
-int lrt_version(void) { return 102; }    // 1.2: bio media fields in lrt_medium_desc, biovolpath integrators, grad_medium in lrt_render_opts
+int lrt_version(void) { return 103; }    // 1.2: bio media fields in lrt_medium_desc, biovolpath integrators, grad_medium in lrt_render_opts; 1.3: lrt_render_stats.lds_resident
 
 static std::vector<std::pair<std::string, std::string>> parse_defines(const char *const *defines, int n) {
     std::vector<std::pair<std::string, std::string>> r;

@@ -712,6 +712,7 @@ void device_render(DeviceScene *D, const lrt_scene_desc &d, const lrt_render_opt
         }
     }
     D->cur_pass_in = nullptr; D->cur_pass_out = nullptr;
+    total.lds_resident = D->use_lds ? 1 : 0;
     stats = total;
     if (image) {
         float *img = image;
