@@ -8,7 +8,6 @@ namespace lrt {
 
 namespace {
 const int kMaxDepth = 22;          // traversal stacks hold 32 (global path) / 24 (LDS path) entries
-const int kLeafSize = 4;
 const int kBins = 16;
 
 struct Box {
@@ -21,7 +20,7 @@ struct Box {
 struct Prim { Box b; float c[3]; uint32_t id; };
 
 struct Builder {
-    const float *pos; const uint32_t *faces; std::vector<Prim> prims; HostBVH &out;
+    const float *pos; const uint32_t *faces; std::vector<Prim> prims; HostBVH &out; int kLeafSize = 4;
     Builder(HostBVH &o) : out(o) {}
 
     Box padded(const Box &b) const {
@@ -75,7 +74,7 @@ struct Builder {
         }
         uint32_t mid;
         if (best_axis < 0) {
-            if (n <= 8) return emit_leaf(b, e, count);          // coincident centroids
+            if (n <= (uint32_t) std::max(8, kLeafSize)) return emit_leaf(b, e, count);          // coincident centroids
             mid = (b + e) / 2;
         } else {
             float ext = cb.hi[best_axis] - cb.lo[best_axis], scale = (float) kBins / ext, lo = cb.lo[best_axis]; int a = best_axis, kb = best_bin;
@@ -100,9 +99,9 @@ struct Builder {
 };
 } // namespace
 
-void build_bvh(const float *positions, const uint32_t *faces, uint32_t n_faces, HostBVH &out) {
+void build_bvh(const float *positions, const uint32_t *faces, uint32_t n_faces, HostBVH &out, int leaf_size) {
     out = HostBVH();
-    Builder B(out); B.pos = positions; B.faces = faces; B.prims.resize(n_faces);
+    Builder B(out); B.kLeafSize = std::max(1, leaf_size); B.pos = positions; B.faces = faces; B.prims.resize(n_faces);
     for (uint32_t f = 0; f < n_faces; ++f) {
         Prim &p = B.prims[f]; p.id = f; p.b.reset();
         for (int k = 0; k < 3; ++k) p.b.grow(positions + 3 * faces[3 * f + k]);

@@ -25,6 +25,8 @@ struct HostBVH {
     int max_depth = 0;
 };
 
-void build_bvh(const float *positions, const uint32_t *faces, uint32_t n_faces, HostBVH &out);
+// leaf_size: the builder splits until a node holds at most this many triangles (4 by default; the device side asks for fatter
+// leaves when that makes the LDS image of a larger mesh fit: device.hip)
+void build_bvh(const float *positions, const uint32_t *faces, uint32_t n_faces, HostBVH &out, int leaf_size = 4);
 
 } // namespace lrt

@@ -54,7 +54,7 @@ struct DeviceScene {
     std::vector<DMedium> h_media; DMedium *d_media = nullptr;
     std::vector<DBioMedium> h_bio; DBioMedium *d_bio = nullptr;
     std::vector<DHetMedium> h_het; DHetMedium *d_het = nullptr; std::vector<float *> het_data; bool has_het = false, has_non_bio = false, need_mis = false, mis_alloc = false;
-    DLdsInfo lds{}; bool use_lds = false; int n_cus = 256;
+    DLdsInfo lds{}; bool use_lds = false; int n_cus = 256; int bvh_leaf = 4;
 
     template <typename T> T *track(T *p) { allocs.push_back((void *) p); return p; }
     void release(void *p) {                // free one tracked allocation now (a workspace that is being replaced by a larger one)
@@ -230,22 +230,43 @@ DeviceScene *device_scene_create(const lrt_scene_desc &d, int device) {
     hipStream_t st = D->stream;
     DScene &sc = D->sc;
     // ---- acceleration structure
-    HostBVH bvh; build_bvh(d.positions, d.faces, d.n_faces, bvh);
+    // LDS a workgroup may ask for: the device's opt-in maximum (160 KiB on gfx950), minus the kernel's static __shared__ words
+    hipDeviceProp_t prop; HIP_CHECK(hipGetDeviceProperties(&prop, device)); D->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    int optin = 0; if (hipDeviceGetAttribute(&optin, hipDeviceAttributeSharedMemPerBlockOptin, device) != hipSuccess || optin <= 0) optin = (int) prop.sharedMemPerBlock;
+    (void) hipGetLastError();
+    const size_t lds_limit = std::min<size_t>((size_t) std::max(optin, 0), 160 * 1024) - 512;
+    // bytes of the LDS image of a BVH: nodes, float4 vertices, 8-byte triangle slots, 16-bit traversal stacks of 1024 threads
+    auto lds_image_bytes = [&](const HostBVH &b) {
+        const size_t nodes_b = b.nodes.size() / 16 * 64, verts_b = ((size_t) d.n_vertices * 16 + 15) & ~size_t(15), tris_b = (b.tris.size() / 12 * 8 + 15) & ~size_t(15);
+        return nodes_b + verts_b + tris_b + (size_t) 2 * (b.max_depth + 2) * 1024;
+    };
+    // Leaves of at most 4 triangles; a mesh whose image does not fit the LDS with those gets fatter leaves (fewer nodes) if that
+    // makes it fit: more triangle tests per leaf, but every fetch of the traversal stays in LDS (Liver-MultiMesh: 90 us -> ... per
+    // query tile against the global-memory path).  LRT_BVH_LEAF=n forces a size.
+    HostBVH bvh;
+    {
+        const int forced = getenv("LRT_BVH_LEAF") ? std::max(1, atoi(getenv("LRT_BVH_LEAF"))) : 0;
+        const bool lds_possible = d.n_faces > 0 && d.n_faces <= 32767 && d.n_vertices <= 65535 && !getenv("LRT_NO_LDS_BVH");
+        int chosen = forced ? forced : 4;
+        build_bvh(d.positions, d.faces, d.n_faces, bvh, chosen);
+        if (!forced && lds_possible && lds_image_bytes(bvh) > lds_limit) {
+            for (int leaf : { 6, 8, 12, 16 }) {
+                HostBVH b2; build_bvh(d.positions, d.faces, d.n_faces, b2, leaf);
+                if (lds_image_bytes(b2) <= lds_limit) { bvh = std::move(b2); chosen = leaf; break; }
+            }
+        }
+        D->bvh_leaf = chosen;
+    }
     sc.nodes = (const float4 *) D->track(dev_upload(bvh.nodes.data(), bvh.nodes.size(), st));
     sc.tris = (const float4 *) D->track(dev_upload(bvh.tris.data(), bvh.tris.size(), st));
     sc.root_is_leaf = bvh.root_is_leaf; sc.root_leaf_first = bvh.root_first; sc.root_leaf_count = bvh.root_count;
     sc.n_faces = d.n_faces; sc.n_emitters = d.n_emitters; sc.one_shape = d.n_shapes == 1;
     // ---- LDS image of the acceleration structure (persistent kernel): used when it fits next to the traversal stacks
     {
-        hipDeviceProp_t prop; HIP_CHECK(hipGetDeviceProperties(&prop, device)); D->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         const size_t n_nodes = bvh.nodes.size() / 16, n_slots = bvh.tris.size() / 12, n_verts = d.n_vertices;
         const size_t nodes_b = n_nodes * 64, verts_b = (n_verts * 16 + 15) & ~size_t(15), tris_b = (n_slots * 8 + 15) & ~size_t(15);
-        const size_t stack_b = (size_t) 2 * LRT_LDS_STACK * 1024, total = nodes_b + verts_b + tris_b + stack_b;
-        // LDS a workgroup may ask for: the device's opt-in maximum (160 KiB on gfx950), minus the kernel's static __shared__ words
-        int optin = 0; if (hipDeviceGetAttribute(&optin, hipDeviceAttributeSharedMemPerBlockOptin, device) != hipSuccess || optin <= 0) optin = (int) prop.sharedMemPerBlock;
-        (void) hipGetLastError();
-        const size_t lds_limit = std::min<size_t>((size_t) std::max(optin, 0), 160 * 1024) - 512;
-        if (d.n_faces > 0 && d.n_faces <= 32767 && n_verts <= 65535 && n_nodes <= 32767 && n_slots <= 32767 && bvh.max_depth < LRT_LDS_STACK && total <= lds_limit && !getenv("LRT_NO_LDS_BVH")) {
+        const size_t total = lds_image_bytes(bvh);                   // the per-lane stacks hold max_depth + 2 entries
+        if (d.n_faces > 0 && d.n_faces <= 32767 && n_verts <= 65535 && n_nodes <= 32767 && n_slots <= 32767 && total <= lds_limit && !getenv("LRT_NO_LDS_BVH")) {
             std::vector<unsigned char> blob(nodes_b + verts_b + tris_b, 0);
             memcpy(blob.data(), bvh.nodes.data(), nodes_b);
             float *v = reinterpret_cast<float *>(blob.data() + nodes_b);
