@@ -356,10 +356,11 @@ def test_multi_pass_render_matches_oracle(mi, orc, case):
 
 # ------------------------------------------------- kernel variants and accelerators
 @pytest.mark.parametrize("env", [dict(LRT_NO_LDS_BVH="1"), dict(LRT_NO_DIST_GRID="1"),
-                                 dict(LRT_NO_NEE_REJECT="1"), dict(LRT_POOL="64"), dict(LRT_DIST_GRID_RES="24")])
+                                 dict(LRT_NO_NEE_REJECT="1"), dict(LRT_POOL="64"), dict(LRT_DIST_GRID_RES="24"),
+                                 dict(LRT_BVH_LEAF="12"), dict(LRT_BVH_LEAF="1", LRT_NO_LDS_BVH="1")])
 def test_kernel_variants_bit_exact(mi, orc, monkeypatch, env):
     """Every build-time decision of the device scene (BVH in LDS or in global memory, distance-field look-ahead, exact NEE
-    rejection, pool size) changes speed only: lanes stay bit-identical to the oracle."""
+    rejection, pool size, leaf size of the BVH) changes speed only: lanes stay bit-identical to the oracle."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     sc = mi.load_file(LIVER_XML, integrator="volpath", spp=16, res_width=256, res_height=144)
