@@ -1,5 +1,5 @@
 #!/bin/bash
-# round-2 closing GPU batch: tests, bench lines of every config, profiles of every config (v14 kernels)
+# round-2 closing GPU batch: GPU tests, bench lines of every config (with CPU baselines), rocprofv3 profiles of the configs named as arguments
 mkdir -p gpurun_out/r02/final
 python -u -m pytest tests -m gpu -q --timeout 300 -p no:cacheprovider -x > gpurun_out/r02/final/tests.log 2>&1; tail -2 gpurun_out/r02/final/tests.log
 python3 bench.py --steps 20 --warmup 3 > gpurun_out/r02/final/bench_c3.json 2> gpurun_out/r02/final/bench_c3.err; head -c 100 gpurun_out/r02/final/bench_c3.json; echo
