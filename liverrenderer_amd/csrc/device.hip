@@ -240,21 +240,23 @@ DeviceScene *device_scene_create(const lrt_scene_desc &d, int device) {
         const size_t nodes_b = b.nodes.size() / 16 * 64, verts_b = ((size_t) d.n_vertices * 16 + 15) & ~size_t(15), tris_b = (b.tris.size() / 12 * 8 + 15) & ~size_t(15);
         return nodes_b + verts_b + tris_b + (size_t) 2 * (b.max_depth + 2) * 1024;
     };
-    // Leaves of at most 4 triangles; a mesh whose image does not fit the LDS with those gets fatter leaves (fewer nodes) if that
-    // makes it fit: more triangle tests per leaf, but every fetch of the traversal stays in LDS (Liver-MultiMesh: 90 us -> ... per
-    // query tile against the global-memory path).  LRT_BVH_LEAF=n forces a size.
+    // Leaf size: the smallest of 2, 3, 4, 6, 8, 12, 16 triangles whose BVH image fits the LDS next to the traversal stacks (fatter
+    // leaves = fewer nodes: more triangle tests per leaf, but every fetch of the traversal stays in LDS; Liver-MultiMesh's two meshes
+    // run 44 % faster with 8-triangle leaves in LDS than with 4-triangle leaves in global memory); 4 when nothing fits.
+    // LRT_BVH_LEAF=n forces a size.
     HostBVH bvh;
     {
         const int forced = getenv("LRT_BVH_LEAF") ? std::max(1, atoi(getenv("LRT_BVH_LEAF"))) : 0;
         const bool lds_possible = d.n_faces > 0 && d.n_faces <= 32767 && d.n_vertices <= 65535 && !getenv("LRT_NO_LDS_BVH");
         int chosen = forced ? forced : 4;
-        build_bvh(d.positions, d.faces, d.n_faces, bvh, chosen);
-        if (!forced && lds_possible && lds_image_bytes(bvh) > lds_limit) {
-            for (int leaf : { 6, 8, 12, 16 }) {
+        bool done = false;
+        if (!forced && lds_possible) {                     // the thinnest leaves whose image still fits (measured: 3 beats 4 by 1 % on the liver; 2 does not fit there)
+            for (int leaf : { 2, 3, 4, 6, 8, 12, 16 }) {
                 HostBVH b2; build_bvh(d.positions, d.faces, d.n_faces, b2, leaf);
-                if (lds_image_bytes(b2) <= lds_limit) { bvh = std::move(b2); chosen = leaf; break; }
+                if (lds_image_bytes(b2) <= lds_limit && b2.nodes.size() / 16 <= 32767 && b2.tris.size() / 12 <= 32767) { bvh = std::move(b2); chosen = leaf; done = true; break; }
             }
         }
+        if (!done) build_bvh(d.positions, d.faces, d.n_faces, bvh, chosen);
         D->bvh_leaf = chosen;
     }
     sc.nodes = (const float4 *) D->track(dev_upload(bvh.nodes.data(), bvh.nodes.size(), st));
