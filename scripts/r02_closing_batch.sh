@@ -7,5 +7,5 @@ for c in c3bio c2 c4 c5 parenchyma multimesh; do
   python3 bench.py --config $c --steps 5 --warmup 1 > gpurun_out/r02/final/bench_$c.json 2> gpurun_out/r02/final/bench_$c.err; echo "$c done: $(head -c 100 gpurun_out/r02/final/bench_$c.json)"
 done
 for c in "$@"; do
-  echo "== profile $c"; scripts/r02_profile.sh r02_v14 $c > gpurun_out/r02/final/prof_$c.txt 2>&1; tail -5 gpurun_out/r02/final/prof_$c.txt
+  echo "== profile $c"; scripts/r02_profile.sh r02_v15 $c > gpurun_out/r02/final/prof_$c.txt 2>&1; tail -5 gpurun_out/r02/final/prof_$c.txt
 done

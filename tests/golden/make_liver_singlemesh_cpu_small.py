@@ -12,3 +12,11 @@ lin = np.where(q <= 0.04045, q / 12.92, ((q + 0.055) / 1.055) ** 2.4)
 small = lin.reshape(135, 8, 240, 8, 3).mean((1, 3))
 np.save(os.path.join(ROOT, "tests", "golden", "reference_liver_singlemesh_cpu_down8.npy"), small.astype(np.float16))
 print(small.shape, small.mean((0, 1)))
+
+# scenes/Liver-SingleMesh/mitsuba3/scene.png: the render of scene.xml at the file's own defaults (854x480, 256 spp) that sits
+# next to the scene file: box-averaged 4x2 -> 120x427x3 float16 (tests/test_bio_oracle.py)
+q = mi.read_image("/root/reference/scenes/Liver-SingleMesh/mitsuba3/scene.png")[..., :3].astype(np.float64)
+lin = np.where(q <= 0.04045, q / 12.92, ((q + 0.055) / 1.055) ** 2.4)
+small = lin.reshape(120, 4, 427, 2, 3).mean((1, 3))
+np.save(os.path.join(ROOT, "tests", "golden", "reference_liver_singlemesh_scene_png_down.npy"), small.astype(np.float16))
+print(small.shape, small.mean((0, 1)))
