@@ -581,7 +581,7 @@ static void finish_stats(DeviceScene *D, LaunchLog &log, hipEvent_t e_begin, hip
             fprintf(stderr, "[lrt] launch %zu: %.3f ms\n", i, ms);
         }
     }
-    stats.kernel_ms = ksum;
+    stats.kernel_ms = ksum; stats.lds_resident = D->use_lds ? 1 : 0;
     if (getenv("LRT_DEBUG_LAUNCH")) for (int r = 0; r < 4; ++r) {
         fprintf(stderr, "[lrt] tile kind %d (0 proven-free, 1 query, 2 surface, 3 fresh): %llu tiles, %.1f ticks/tile (100 MHz wall clock)\n", r, D->h_counters->prof_tiles[r], D->h_counters->prof_tiles[r] ? (double) D->h_counters->prof_cycles[r] / D->h_counters->prof_tiles[r] : 0.0);
     }
