@@ -123,7 +123,6 @@ struct LdsScene {
     const float4 *nodes; const float4 *verts; const uint2 *tris;
     uint32_t n_faces, root_is_leaf, root_first, root_count;
 };
-#define LRT_LDS_STACK 24
 #define LRT_LDS_BLOCK_MAX 1024
 
 // `ix` = the slot's index words: three 16-bit vertex indices, then (face index << 1 | last-slot-of-the-leaf flag)

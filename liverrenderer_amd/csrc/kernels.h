@@ -25,8 +25,8 @@ struct PathState {
 };
 
 // BIO: a queued path's ray always comes from spawn_ray (maxt = largest float), so its maxt slot carries si_t instead, and
-// the seventh stream holds tissueDepth (92 B records)
-// MODE: 0 path / volpath (88 B), 1 biovolpath* (92 B), 2 volpath with heterogeneous media (104 B), 3 volpathmis (168 B)
+// the seventh stream holds tissueDepth and the element competition the look-ahead already ran (96 B records)
+// MODE: 0 path / volpath (88 B), 1 biovolpath* (96 B), 2 volpath with heterogeneous media (104 B), 3 volpathmis (168 B)
 template <int MODE = 0, typename QS>
 DEV void load_state(const QS &q, size_t i, PathState &s) {
     float4 a = q.o_maxt[i], b = q.d_eta[i], c = q.tp_pdf[i], d = q.res_flags[i], e = q.lp_lane[i]; uint2 r = q.rng[i];
