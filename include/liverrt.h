@@ -274,7 +274,10 @@ LRT_API lrt_status lrt_trace(lrt_scene *scene, const lrt_rays_soa *rays,
 
 /* Keys follow mi.traverse(): "<medium id>.sigma_t.value" (3 floats),
  * "<medium id>.albedo.value" (3), "<medium id>.scale" (1),
- * "<medium id>.phase_function.g" (1; switches the phase to HG when != 0).   */
+ * "<medium id>.phase_function.g" (1; switches the phase to HG when != 0);
+ * a `parenchyma` medium also has what src/media/parenchyma.cpp:154-160 traverses:
+ * "<id>.sigma_blood.value", "<id>.sigma_bile.value", "<id>.sigma_lipid_water.value" (3 each)
+ * and "<id>.sigma_hepatocity" (1).                                           */
 LRT_API lrt_status lrt_param_set(lrt_scene *scene, const char *key, const float *v, int n);
 LRT_API lrt_status lrt_param_get(const lrt_scene *scene, const char *key, float *v, int n);
 

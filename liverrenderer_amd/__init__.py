@@ -324,6 +324,13 @@ class SceneParameters(dict):
             super().__setitem__(f"{mid}.albedo.value", scene.param_get(f"{mid}.albedo.value", 3))
             super().__setitem__(f"{mid}.scale", scene.param_get(f"{mid}.scale", 1))
             super().__setitem__(f"{mid}.phase_function.g", scene.param_get(f"{mid}.phase_function.g", 1))
+        for i in range(scene.desc.n_media):                   # `parenchyma` also traverses its absorbers (src/media/parenchyma.cpp:154-160)
+            m = scene.desc.media[i]
+            if m.type == _lib.MEDIUM["parenchyma"]:
+                mid = m.id.decode()
+                for k in ("sigma_blood.value", "sigma_bile.value", "sigma_lipid_water.value"):
+                    super().__setitem__(f"{mid}.{k}", scene.param_get(f"{mid}.{k}", 3))
+                super().__setitem__(f"{mid}.sigma_hepatocity", scene.param_get(f"{mid}.sigma_hepatocity", 1))
         self._dirty = set()
 
     def __setitem__(self, k, v):

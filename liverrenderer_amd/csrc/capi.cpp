@@ -221,6 +221,15 @@ lrt_status lrt_param_set(lrt_scene *scene, const char *key, const float *v, int 
         float *dst = rest[0] == 's' ? M->sigma_t : M->albedo;
         for (int i = 0; i < 3; ++i) dst[i] = v[n == 3 ? i : 0];
     } else if (!strcmp(rest, "scale")) M->scale = v[0];
+    else if (M->type == LRT_MEDIUM_PARENCHYMA && (!strcmp(rest, "sigma_blood.value") || !strcmp(rest, "sigma_bile.value") || !strcmp(rest, "sigma_lipid_water.value"))) {
+        // what `parenchyma` puts into mi.traverse (src/media/parenchyma.cpp:154-160): the absorbers' coefficients and sigma_hepatocity
+        if (n != 1 && n != 3) return fail(LRT_ERR_INVALID, "expected 1 or 3 values");
+        float *dst;
+        if (!strncmp(rest, "sigma_bile", 10)) dst = M->sigma_bile;
+        else if (!strncmp(rest, "sigma_blood", 11)) dst = M->sigma_blood;
+        else dst = M->sigma_lipid_water;
+        for (int i = 0; i < 3; ++i) dst[i] = v[n == 3 ? i : 0];
+    } else if (M->type == LRT_MEDIUM_PARENCHYMA && !strcmp(rest, "sigma_hepatocity")) M->sigma_hepatocity = v[0];
     else if (!strcmp(rest, "phase_function.g")) {
         // mi.traverse exposes `g` for an hg phase function only (src/phase/hg.cpp:60-62; isotropic.cpp has no parameter).  The
         // one extension kept from round 1: a NON-ZERO g on an isotropic medium turns it into hg ("HG variant ...
@@ -241,6 +250,10 @@ lrt_status lrt_param_get(const lrt_scene *scene, const char *key, float *v, int 
     else if (!strcmp(rest, "albedo.value")) { for (int i = 0; i < n && i < 3; ++i) v[i] = M->albedo[i]; }
     else if (!strcmp(rest, "scale")) v[0] = M->scale;
     else if (!strcmp(rest, "phase_function.g")) v[0] = M->g;
+    else if (M->type == LRT_MEDIUM_PARENCHYMA && !strcmp(rest, "sigma_blood.value")) { for (int i = 0; i < n && i < 3; ++i) v[i] = M->sigma_blood[i]; }
+    else if (M->type == LRT_MEDIUM_PARENCHYMA && !strcmp(rest, "sigma_bile.value")) { for (int i = 0; i < n && i < 3; ++i) v[i] = M->sigma_bile[i]; }
+    else if (M->type == LRT_MEDIUM_PARENCHYMA && !strcmp(rest, "sigma_lipid_water.value")) { for (int i = 0; i < n && i < 3; ++i) v[i] = M->sigma_lipid_water[i]; }
+    else if (M->type == LRT_MEDIUM_PARENCHYMA && !strcmp(rest, "sigma_hepatocity")) v[0] = M->sigma_hepatocity;
     else return fail(LRT_ERR_INVALID, std::string("unknown parameter \"") + key + "\"");
     return LRT_OK;
 }

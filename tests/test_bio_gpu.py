@@ -137,3 +137,23 @@ def test_liver_multimesh_full_scene(mi, orc):
     img = mi.load_string(xml, base_dir=base, spp=256, res_width=240, res_height=135).render().astype(np.float64)[..., :3]
     ours, ref, iou, bg = interior_colour(img, golden, env)
     assert iou > 0.99 and bg < 1e-3 and np.allclose(ours, ref, rtol=0.015), (ours, ref)
+
+
+def test_parenchyma_traverse_parameters(mi, orc):
+    """mi.traverse on a `parenchyma` medium (src/media/parenchyma.cpp:154-160): the absorbers' coefficients and sigma_hepatocity are
+    parameters; an update reaches the device (lanes change and stay bit-identical to the oracle on the updated description)."""
+    sc = mi.load_file(PARENCHYMA_XML, spp=16, res_width=96, res_height=54)
+    p = mi.traverse(sc)
+    mid = sc.desc.media[0].id.decode()
+    for k in ("sigma_blood.value", "sigma_bile.value", "sigma_lipid_water.value", "sigma_hepatocity", "scale"):
+        assert f"{mid}.{k}" in p
+    assert np.allclose(p[f"{mid}.sigma_hepatocity"], sc.desc.media[0].sigma_hepatocity)
+    before = sc.render_samples(0, 96 * 54 * 16)
+    p[f"{mid}.sigma_hepatocity"] = 12.5
+    p[f"{mid}.sigma_blood.value"] = [0.3, 0.05, 0.02]
+    p.update()
+    assert sc.desc.media[0].sigma_hepatocity == 12.5 and list(sc.desc.media[0].sigma_blood) == pytest.approx([0.3, 0.05, 0.02])
+    after = assert_lanes_equal(sc, orc.OrcScene(sc), 0, 96 * 54 * 16)
+    assert (before != after).any()
+    with pytest.raises(RuntimeError, match="unknown parameter"):
+        mi.load_file(LIVER_XML).param_set("LiverMedium.sigma_blood.value", [1, 1, 1])     # `liver` traverses scale, albedo, sigma_t only
