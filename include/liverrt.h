@@ -295,6 +295,38 @@ LRT_API lrt_status lrt_image_write_exr(const char *path, int width, int height, 
  * with its PNGs to within one code value.                                                    */
 LRT_API lrt_status lrt_image_write_png(const char *path, int width, int height, int channels, const float *data);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * Learned subsurface model, network stage only: the shape-adaptive scatter network of
+ * include/mitsuba/render/scattereigen.h:249-480 (ScatterModelSimShared<3, 4, 64, 64>::run): feature MLP 23 -> 64 -> 64 -> 64,
+ * absorption head 64 -> 32 -> 1 (sigmoid, one sampler draw), decoder (4 Gaussian latents + 64) -> 64 -> 64 -> 64 -> 3, result
+ * mapped from the tangent frame of -in_dir to world space and scaled by 1 / fit_scale.  docs/SUBSURFACE_NOTES.md explains
+ * why the plugin around it (src/subsurface/vaescatter.cpp) is not built.
+ *
+ * Weights: one float32 blob in this order (row-major matrices, rows = outputs), as the .bin files of
+ * pysrc/outputs/vae3d/models/<model>/variables/ hold them, preceded by the normalisation statistics of
+ * pysrc/outputs/vae3d/datasets/<dataset>/train/data_stats.json ("effAlbedo", "g", "mlsPoly3"):                       */
+#define LRT_VAE_STATS        0      /* albedo mean, albedo 1/std, g mean, g 1/std, shape mean[20], shape 1/std[20]        */
+#define LRT_VAE_PRE0_W      44      /* shared_preproc_mlp_2_shapemlp_fcn_0_weights [64][23], then _biases [64]            */
+#define LRT_VAE_PRE1_W    (LRT_VAE_PRE0_W + 64 * 23 + 64)      /* fcn_1 [64][64] + [64]                                   */
+#define LRT_VAE_PRE2_W    (LRT_VAE_PRE1_W + 64 * 64 + 64)      /* fcn_2 [64][64] + [64]                                   */
+#define LRT_VAE_ABS0_W    (LRT_VAE_PRE2_W + 64 * 64 + 64)      /* absorption_mlp_fcn_0 [32][64] + [32]                    */
+#define LRT_VAE_ABSD_K    (LRT_VAE_ABS0_W + 32 * 64 + 32)      /* absorption_dense_kernel [32] + bias [1]                 */
+#define LRT_VAE_DEC0_W    (LRT_VAE_ABSD_K + 32 + 1)            /* scatter_decoder_fcn_fcn_0 [64][68] + [64]               */
+#define LRT_VAE_DEC1_W    (LRT_VAE_DEC0_W + 64 * 68 + 64)      /* fcn_1 [64][64] + [64]                                   */
+#define LRT_VAE_DEC2_W    (LRT_VAE_DEC1_W + 64 * 64 + 64)      /* fcn_2 [64][64] + [64]                                   */
+#define LRT_VAE_OUT_K     (LRT_VAE_DEC2_W + 64 * 64 + 64)      /* scatter_dense_2_kernel [3][64] + bias [3]               */
+#define LRT_VAE_N_FLOATS  (LRT_VAE_OUT_K + 3 * 64 + 3)
+typedef struct lrt_vae_model lrt_vae_model;
+LRT_API lrt_status lrt_vae_model_create(const float *blob, uint64_t n_floats, lrt_vae_model **out);
+LRT_API void       lrt_vae_model_free(lrt_vae_model *model);
+/* n samples; sample i uses in_pos[3i..], in_dir[3i..], poly_coeffs[20i..] (the order-3 polynomial of the surface around in_pos,
+ * in the network's "LS" space) and its own PCG32 stream seeded like a render lane (TEA(seed, i)).  Outputs: out_pos[3i..] and
+ * out_absorption[i] (1: the sample was absorbed, out_pos = in_pos; 0: out_pos is the predicted exit point).  Host pointers. */
+LRT_API lrt_status lrt_vae_scatter(lrt_vae_model *model, uint32_t n, const float *in_pos, const float *in_dir,
+                                   const float *poly_coeffs, const float albedo[3], float g, float ior,
+                                   const float sigma_t[3], float fit_scale, uint32_t seed,
+                                   float *out_pos, float *out_absorption, int device);
+
 #ifdef __cplusplus
 }
 #endif

@@ -158,7 +158,8 @@ def lib():
 EXPORTED_SYMBOLS = ["lrt_last_error", "lrt_version", "lrt_scene_load_xml", "lrt_scene_load_xml_string", "lrt_scene_from_desc",
                     "lrt_scene_desc_get", "lrt_scene_free", "lrt_render", "lrt_render_stats_get", "lrt_film_develop",
                     "lrt_render_samples", "lrt_render_backward", "lrt_trace", "lrt_param_set", "lrt_param_get",
-                    "lrt_image_read", "lrt_image_free", "lrt_image_write_exr", "lrt_image_write_png"]
+                    "lrt_image_read", "lrt_image_free", "lrt_image_write_exr", "lrt_image_write_png",
+                    "lrt_vae_model_create", "lrt_vae_model_free", "lrt_vae_scatter"]
 
 
 def check(status):

@@ -273,6 +273,28 @@ lrt_status lrt_image_read(const char *path, int *width, int *height, int *channe
 
 void lrt_image_free(float *data) { free(data); }
 
+// ---- learned subsurface model, network stage
+struct lrt_vae_model { std::vector<float> blob; };
+
+lrt_status lrt_vae_model_create(const float *blob, uint64_t n_floats, lrt_vae_model **out) {
+    if (!blob || !out) return fail(LRT_ERR_INVALID, "lrt_vae_model_create: null argument");
+    if (n_floats != (uint64_t) LRT_VAE_N_FLOATS) return fail(LRT_ERR_INVALID, "lrt_vae_model_create: expected " + std::to_string(LRT_VAE_N_FLOATS) + " floats (include/liverrt.h)");
+    for (uint64_t i = 0; i < n_floats; ++i) if (!std::isfinite(blob[i])) return fail(LRT_ERR_INVALID, "lrt_vae_model_create: non-finite weight");
+    lrt_vae_model *m = new lrt_vae_model(); m->blob.assign(blob, blob + n_floats); *out = m;
+    return LRT_OK;
+}
+void lrt_vae_model_free(lrt_vae_model *model) { delete model; }
+
+lrt_status lrt_vae_scatter(lrt_vae_model *model, uint32_t n, const float *in_pos, const float *in_dir, const float *poly_coeffs, const float albedo[3], float g, float ior,
+                           const float sigma_t[3], float fit_scale, uint32_t seed, float *out_pos, float *out_absorption, int device) {
+    if (!model || !albedo || !sigma_t || (n && (!in_pos || !in_dir || !poly_coeffs || !out_pos || !out_absorption))) return fail(LRT_ERR_INVALID, "lrt_vae_scatter: null argument");
+    if (!(fit_scale > 0.f)) return fail(LRT_ERR_INVALID, "lrt_vae_scatter: fit_scale must be positive");
+    LRT_TRY
+        device_vae_scatter(model->blob.data(), n, in_pos, in_dir, poly_coeffs, albedo, g, ior, sigma_t, fit_scale, seed, out_pos, out_absorption, device);
+        return LRT_OK;
+    LRT_CATCH
+}
+
 lrt_status lrt_image_write_exr(const char *path, int width, int height, int channels, const float *data) {
     if (!path || !data) return fail(LRT_ERR_INVALID, "lrt_image_write_exr: null argument");
     LRT_TRY

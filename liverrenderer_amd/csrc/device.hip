@@ -4,6 +4,7 @@
 #include "host_scene.h"
 #include "device_scene.h"
 #include "kernels_prb.h"
+#include "kernels_vae.h"
 #include "bvh.h"
 #include <cmath>
 #include <array>
@@ -881,6 +882,34 @@ void device_render_backward(DeviceScene *D, const lrt_scene_desc &d, const lrt_r
     HIP_CHECK(hipMemcpy(h, D->d_grads, sizeof(h), hipMemcpyDeviceToHost));
     for (int k = 0; k < 3; ++k) { out->d_sigma_t[k] = (float) h[k]; out->d_albedo[k] = (float) h[3 + k]; }
     out->d_g = (float) h[6];
+}
+
+// ---- learned subsurface model, network stage (include/liverrt.h; one lane per sample, weights through the scalar cache)
+void device_vae_scatter(const float *blob, uint32_t n, const float *in_pos, const float *in_dir, const float *poly, const float albedo[3], float g, float ior,
+                        const float sigma_t[3], float fit_scale, uint32_t seed, float *out_pos, float *out_absorption, int device) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count == 0)
+        throw std::runtime_error("no HIP device available: the hip_ad_rgb back-end has no CPU fallback");
+    if (device < 0 || device >= count) throw std::runtime_error("invalid HIP device ordinal " + std::to_string(device));
+    HIP_CHECK(hipSetDevice(device));
+    if (n == 0) return;
+    // the medium-level features are the same for every sample: evaluated once, on the device (one thread), with the kernels' own log / exp
+    struct Tmp { float *p = nullptr; ~Tmp() { if (p) (void) hipFree(p); } };
+    Tmp d_blob, d_pos, d_dir, d_poly, d_opos, d_oabs, d_feat;
+    auto up = [&](Tmp &t, const float *src, size_t cnt) { HIP_CHECK(hipMalloc((void **) &t.p, cnt * sizeof(float))); if (src) HIP_CHECK(hipMemcpy(t.p, src, cnt * sizeof(float), hipMemcpyHostToDevice)); };
+    up(d_blob, blob, LRT_VAE_N_FLOATS); up(d_pos, in_pos, 3 * (size_t) n); up(d_dir, in_dir, 3 * (size_t) n); up(d_poly, poly, 20 * (size_t) n);
+    up(d_opos, nullptr, 3 * (size_t) n); up(d_oabs, nullptr, n); up(d_feat, nullptr, 4);
+    k_vae_medium_features<<<1, 1>>>(d_blob.p, albedo[0], albedo[1], albedo[2], g, ior, sigma_t[0], sigma_t[1], sigma_t[2], d_feat.p);
+    HIP_CHECK(hipGetLastError());
+    float feat[4]; HIP_CHECK(hipMemcpy(feat, d_feat.p, sizeof feat, hipMemcpyDeviceToHost));
+    DVaeArgs A{}; A.blob = d_blob.p; A.in_pos = d_pos.p; A.in_dir = d_dir.p; A.poly = d_poly.p; A.out_pos = d_opos.p; A.out_absorption = d_oabs.p;
+    A.albedo_norm = feat[0]; A.g_norm = feat[1]; A.ior_norm = feat[2]; A.fit_scale = fit_scale; A.n = n; A.seed = seed;
+    const size_t smem = (size_t) 2 * 68 * LRT_VAE_BLOCK * sizeof(float);
+    HIP_CHECK(hipFuncSetAttribute((const void *) k_vae_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem));
+    k_vae_scatter<<<(n + LRT_VAE_BLOCK - 1) / LRT_VAE_BLOCK, LRT_VAE_BLOCK, smem>>>(A);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipMemcpy(out_pos, d_opos.p, 3 * (size_t) n * sizeof(float), hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(out_absorption, d_oabs.p, (size_t) n * sizeof(float), hipMemcpyDeviceToHost));
 }
 
 } // namespace lrt

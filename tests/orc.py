@@ -188,3 +188,17 @@ def math_eval(fn, x, y=None):
     out = np.empty_like(x); out2 = np.empty_like(x)
     lib().orc_math_eval(fn, _fp(x), _fp(y), x.size, _fp(out), _fp(out2))
     return out, out2
+
+
+def vae_scatter(blob, in_pos, in_dir, poly, albedo, g, ior, sigma_t, fit_scale, seed=0):
+    """oracle/orc_vae.cpp: the network stage of the learned subsurface model on the CPU (same argument meaning as lrt_vae_scatter)"""
+    f = lambda a, shape: np.ascontiguousarray(np.asarray(a, np.float32).reshape(shape))
+    n = int(np.asarray(in_pos).reshape(-1, 3).shape[0])
+    b, ip, idr, pc, al, sg = f(blob, (-1,)), f(in_pos, (n, 3)), f(in_dir, (n, 3)), f(poly, (n, 20)), f(albedo, (3,)), f(sigma_t, (3,))
+    out, ab = np.zeros((n, 3), np.float32), np.zeros(n, np.float32)
+    L = lib()
+    L.orc_vae_scatter.argtypes = [C.POINTER(C.c_float), C.c_uint32] + [C.POINTER(C.c_float)] * 4 + [C.c_float, C.c_float, C.POINTER(C.c_float), C.c_float, C.c_uint32,
+                                  C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.orc_vae_scatter.restype = None
+    L.orc_vae_scatter(_fp(b), n, _fp(ip), _fp(idr), _fp(pc), _fp(al), float(g), float(ior), _fp(sg), float(fit_scale), int(seed), _fp(out), _fp(ab))
+    return out, ab
