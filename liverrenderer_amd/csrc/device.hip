@@ -598,9 +598,9 @@ static PoolGeometry pool_geometry(DeviceScene *D, uint64_t n_lanes) {
     const uint32_t pool_max = getenv("LRT_POOL") ? std::max(64, atoi(getenv("LRT_POOL"))) : (D->use_lds ? 32768u : 8192u);
     g.P = (uint32_t) std::min<uint64_t>(pool_max, std::max<uint64_t>(64, ((n_lanes + g.n_wg - 1) / g.n_wg + 63) / 64 * 64));
     // a launch with few lanes per workgroup (a rank's share of the frame at 8 GPUs: ~0.5 M) spends a visible part of its time
-    // filling and draining the pool: about 24 pool turnovers per workgroup were measured best (1/8 frame: +1.5 % over the full pool)
+    // filling and draining the pool: pools of 8 K - 16 K paths were measured best for a 1/8 share of C3 (31.5 ms against 32.4 ms with the full pool): the pool follows the launch, about 48 turnovers per workgroup
     if (!getenv("LRT_POOL") && D->use_lds) {
-        const uint64_t per_wg = (n_lanes + g.n_wg - 1) / g.n_wg, want = (per_wg / 24 + 63) / 64 * 64;
+        const uint64_t per_wg = (n_lanes + g.n_wg - 1) / g.n_wg, want = (per_wg / 48 + 63) / 64 * 64;
         if (want < g.P) g.P = (uint32_t) std::max<uint64_t>(want, std::min<uint64_t>(g.P, 8192));
     }
     g.block = D->use_lds ? 1024u : (uint32_t) LRT_BLOCK;

@@ -135,7 +135,7 @@ DEV Ray camera_ray(SceneRef sc, float ax, float ay) {
 template <bool LD>
 DEV PathState generate_camera_path(SceneRef sc, RpRef rp, const uint32_t *__restrict__ pixel_list, uint64_t j) {
     uint32_t lane;
-    if (pixel_list) { uint32_t pj = (uint32_t) (j / rp.spp); lane = pixel_list[pj] * rp.spp + (uint32_t) (j - (uint64_t) pj * rp.spp); }
+    if (pixel_list) { uint32_t pj = (rp.log2_spp != 0xffffffffu) ? (uint32_t) (j >> rp.log2_spp) : (uint32_t) (j / rp.spp); lane = pixel_list[pj] * rp.spp + (uint32_t) (j - (uint64_t) pj * rp.spp); }
     else lane = (uint32_t) j;
     SamplerT<LD> rng = lane_rng_pass_start<LD>(rp, lane, j);
     int px, py; lane_to_pixel(sc, rp, lane, &px, &py);
@@ -892,7 +892,7 @@ k_splat_lanes(ScenePtr scp, LaunchPtr lp) {
     if (have) {
         const uint64_t j = slot_base + i;
         uint32_t lane;
-        if (pixel_list) { uint32_t pj = (uint32_t) (j / rp.spp); lane = pixel_list[pj] * rp.spp + (uint32_t) (j - (uint64_t) pj * rp.spp); }
+        if (pixel_list) { uint32_t pj = (rp.log2_spp != 0xffffffffu) ? (uint32_t) (j >> rp.log2_spp) : (uint32_t) (j / rp.spp); lane = pixel_list[pj] * rp.spp + (uint32_t) (j - (uint64_t) pj * rp.spp); }
         else lane = (uint32_t) j;
         if (!WEIGHTS_ONLY) {
             const float4 v = lane_L[i];
