@@ -586,6 +586,11 @@ static void finish_stats(DeviceScene *D, LaunchLog &log, hipEvent_t e_begin, hip
     if (getenv("LRT_DEBUG_LAUNCH")) for (int r = 0; r < 4; ++r) {
         fprintf(stderr, "[lrt] tile kind %d (0 proven-free, 1 query, 2 surface, 3 fresh): %llu tiles, %.1f ticks/tile (100 MHz wall clock)\n", r, D->h_counters->prof_tiles[r], D->h_counters->prof_tiles[r] ? (double) D->h_counters->prof_cycles[r] / D->h_counters->prof_tiles[r] : 0.0);
     }
+    if (getenv("LRT_DEBUG_LAUNCH") && D->h_counters->prof_wg[1]) {
+        const unsigned long long *w = D->h_counters->prof_wg; const double n_wg = D->use_lds ? D->n_cus : 4.0 * D->n_cus, first = (double) ~w[2];
+        fprintf(stderr, "[lrt] workgroups (last launch; us): first start 0, last start %.1f, last end %.1f, mean run time %.1f, mean LDS-image copy %.1f, mean barrier wait per wave %.1f\n",
+                ((double) w[5] - first) / 100.0, ((double) w[1] - first) / 100.0, (double) w[3] / n_wg / 100.0, (double) w[0] / n_wg / 100.0, (double) w[4] / (n_wg * (D->use_lds ? 16.0 : 4.0)) / 100.0);
+    }
     HIP_CHECK(hipEventElapsedTime(&ms, e_begin, e_end)); stats.total_ms = ms;
 }
 

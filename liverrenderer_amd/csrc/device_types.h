@@ -195,6 +195,7 @@ struct DCounters {             // device-resident queue / statistics words
     unsigned long long next_lane;  // global camera-lane ticket (render kernel)
     unsigned long long n_records;  // path records loaded from the queues
     unsigned long long prof_cycles[4], prof_tiles[4];   // per tile kind (A, C, B, fresh): wall_clock64 ticks and tiles (LRT_DEBUG_LAUNCH)
+    unsigned long long prof_wg[6];   // LRT_DEBUG_LAUNCH: workgroup timeline, 100 MHz ticks: sum of start, sum of (loop start - start), sum of end, max end, min start + 2^62 trick see kernels.h, sum of barrier waits of thread 0
 };
 
 // LDS image of the scene for the persistent traversal kernel: [nodes | verts (float4) | tris (4 x u16)] copied verbatim

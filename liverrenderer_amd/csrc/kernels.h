@@ -714,6 +714,8 @@ k_render(ScenePtr scp, LaunchPtr lp) {
     const uint32_t tid = threadIdx.x, lane_in_wave = tid & 63u;
     constexpr int MODE = (INTEGRATOR == LRT_INTEGRATOR_BIOVOLPATH || INTEGRATOR == LRT_INTEGRATOR_BIOVOLPATH06) ? 1 : (INTEGRATOR == LRT_INTEGRATOR_VOLPATH_HET ? 2 : ((INTEGRATOR == LRT_INTEGRATOR_VOLPATHMIS || INTEGRATOR == LRT_INTEGRATOR_VOLPATHMIS_PLAIN) ? 3 : 0));
     if (tid < 8) s_prof[tid] = 0;
+    const unsigned long long t_wg_start = (rp.profile & 1u) ? wall_clock64() : 0ull;
+    unsigned long long t_loop_start = 0ull, t_barrier = 0ull;
     LdsScene L{};
     if (LDS_BVH) {
         const uint4 *src = li.blob; uint4 *dst = reinterpret_cast<uint4 *>(smem);
@@ -729,6 +731,7 @@ k_render(ScenePtr scp, LaunchPtr lp) {
     if (tid == 0) { s_in[0] = s_in[1] = s_in[2] = 0; }
     bool lanes_left = true;                                   // thread 0
     uint32_t n_shadow = 0, n_extra = 0, n_trips = 0, n_loaded = 0;
+    if (rp.profile & 1u) t_loop_start = wall_clock64();
     for (;;) {
         if (tid == 0) {
             const uint32_t want = P - (s_in[0] + s_in[1] + s_in[2]);
@@ -809,9 +812,16 @@ k_render(ScenePtr scp, LaunchPtr lp) {
                 atomicAdd(&s_prof[region], wall_clock64() - t_begin); atomicAdd(&s_prof[4 + region], 1ull);
             }
         }
+        { const unsigned long long tb0 = (rp.profile & 1u) ? wall_clock64() : 0ull;
         __syncthreads();
+        if (rp.profile & 1u) t_barrier += wall_clock64() - tb0; }
         if (tid == 0) { s_in[0] = s_out[0]; s_in[1] = s_out[1]; s_in[2] = s_out[2]; }
         parity ^= 1u;
+    }
+    if ((rp.profile & 1u) && (tid & 63u) == 0) {              // workgroup timeline; barrier waits summed over the 16 waves' first lanes
+        const unsigned long long t_end = wall_clock64();
+        if (tid == 0) { atomicAdd(&A.cnt->prof_wg[0], t_loop_start - t_wg_start); atomicMax(&A.cnt->prof_wg[1], t_end); atomicMax(&A.cnt->prof_wg[2], ~t_wg_start); atomicAdd(&A.cnt->prof_wg[3], t_end - t_wg_start); atomicMax(&A.cnt->prof_wg[5], t_wg_start); }
+        atomicAdd(&A.cnt->prof_wg[4], t_barrier);
     }
     if ((rp.profile & 1u) && tid < 8) { if (tid < 4) atomicAdd(&A.cnt->prof_cycles[tid], s_prof[tid]); else atomicAdd(&A.cnt->prof_tiles[tid - 4], s_prof[tid]); }
     n_trips += n_extra;
