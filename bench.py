@@ -5,6 +5,7 @@ A "step" is one complete render of the workload (ray generation -> persistent sa
 film all-reduce when N > 1).  Default workload (`--config c3`): BASELINE config C3 = scenes/Liver-SingleMesh, plain
 `volpath`, 1920x1080, 512 spp, max_depth 12.  Other single-GPU workloads of BASELINE.json, each with its own roofline:
 
+  --config c3hg         C3 with the medium's phase function set to Henyey-Greenstein, g = 0.7 (BASELINE.json config 3 names "HG phase")
   --config c3bio        the same scene file with its OWN defaults' integrator and medium (`biovolpath` + `liver`), the
                         transport every published timing of the reference is quoted on
   --config c2           mi.cornell_box() at 1080x1080, `path`, 256 spp (Gaussian filter)
@@ -39,6 +40,11 @@ KERNEL_ID = {"path": 0, "volpath": 1, "biovolpath": 3, "biovolpath06": 4}
 CONFIGS = {
     "c3": dict(scene=os.path.join(SCENES, "Liver-SingleMesh", "mitsuba3", "scene.xml"), integrator="volpath", spp=512, width=1920, height=1080,
                label="C3 Liver-SingleMesh {integrator} {w}x{h} {spp} spp max_depth 12 (homogeneous medium, isotropic phase, envmap)"),
+    # BASELINE.json config 3 names "homogeneous medium + HG phase": the same workload with the medium's phase function set to HG, g = 0.7,
+    # through the reference's own parameter interface (mi.traverse; BASELINE.md C3 "HG g=0.7 as a second run")
+    "c3hg": dict(scene=os.path.join(SCENES, "Liver-SingleMesh", "mitsuba3", "scene.xml"), integrator="volpath", spp=512, width=1920, height=1080,
+                 params={"LiverMedium.phase_function.g": 0.7},
+                 label="C3 Liver-SingleMesh {integrator} {w}x{h} {spp} spp max_depth 12 (homogeneous medium, HG phase g = 0.7, envmap)"),
     "c3bio": dict(scene=os.path.join(SCENES, "Liver-SingleMesh", "mitsuba3", "scene.xml"), integrator=None, spp=512, width=1920, height=1080,
                   label="C3-bio Liver-SingleMesh {integrator} (file defaults: liver medium) {w}x{h} {spp} spp max_depth 12"),
     "c2": dict(scene="cornell_box", integrator="path", spp=256, width=1080, height=1080,
@@ -100,7 +106,12 @@ def load(mi, cfg, spp, w, h, integrator):
         return mi.load_dict(d)
     kw = dict(spp=spp, res_width=w, res_height=h)
     if integrator: kw["integrator"] = integrator
-    return mi.load_file(cfg["scene"], **kw)
+    scene = mi.load_file(cfg["scene"], **kw)
+    if cfg.get("params"):
+        p = mi.traverse(scene)
+        for k, v in cfg["params"].items(): p[k] = v
+        p.update()
+    return scene
 
 
 def main():
