@@ -376,3 +376,24 @@ def test_loader_against_independent_python_parse(mi):
     R = 2 * np.outer(a, a) - np.eye(3)
     E = np.eye(4); E[:3, :3] = R; E[:3, 3] = R @ np.array([-3, 3, 4])
     assert np.allclose(np.array(d.emitters[0].to_world).reshape(4, 4), E, atol=1e-6)
+
+
+def test_bench_configs_load_on_the_host(mi):
+    """Every workload bench.py names resolves to a scene that loads with the spp / size / integrator / parameters the config asks for
+    (no GPU needed: loading is host code); guards the table the driver's bench run depends on."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    from liverrenderer_amd import _lib
+    names = {v: k for k, v in _lib.INTEGRATOR.items()}
+    for key, cfg in bench.CONFIGS.items():
+        sc = bench.load(mi, cfg, 4, 64, 36, cfg["integrator"])
+        h, w, _ = sc.film_shape()
+        assert (w, h) == (64, 36), key
+        integ = names[sc.desc.integrator.type]
+        if cfg["integrator"]: assert integ == cfg["integrator"], key
+        assert integ in bench.RECORD_BYTES, key
+        if integ != "prbvolpath": assert integ in bench.KERNEL_ID, key
+        for k, v in (cfg.get("params") or {}).items():
+            assert np.allclose(mi.traverse(sc)[k], v), (key, k)
+    assert bench.CONFIGS["c3hg"]["params"]["LiverMedium.phase_function.g"] == 0.7
