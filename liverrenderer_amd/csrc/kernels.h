@@ -1003,4 +1003,91 @@ k_trace_lds(ScenePtr scp, DLdsInfo li, const float *ox, const float *oy, const f
     }
 }
 
+#ifdef LRT_EXPERIMENT
+// Developer experiment (`make exp`, LRT_TRACE_REFILL=M in device_trace): the closest-hit queries of k_trace_lds with lane refill inside the
+// traversal.  A wave owns M consecutive rays; rays 64.. wait in LDS, and a lane whose query is finished stores its hit and takes the next
+// waiting ray before the wave goes back to the node loop, so the idle tail comes once per M rays instead of once per 64.  Same arithmetic
+// as trace_lds (hits must be identical); measures what a two-sub-tile query tile of k_render could gain.
+template <int M>
+__global__ void __launch_bounds__(1024)
+k_trace_lds_refill(ScenePtr scp, DLdsInfo li, uint32_t list_off, const float *ox, const float *oy, const float *oz, const float *dx, const float *dy, const float *dz, const float *tmax,
+                   float *t, float *u, float *v, uint32_t *prim, uint32_t n) {
+    SceneRef sc = *scp;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    {
+        const uint4 *src = li.blob; uint4 *dst = reinterpret_cast<uint4 *>(smem);
+        for (uint32_t k = tid; k < li.blob_bytes / 16u; k += 1024) dst[k] = src[k];
+    }
+    LdsScene L;
+    L.nodes = reinterpret_cast<const float4 *>(smem + li.nodes_off); L.verts = reinterpret_cast<const float4 *>(smem + li.verts_off);
+    L.tris = reinterpret_cast<const uint2 *>(smem + li.tris_off);
+    L.n_faces = sc.n_faces;
+    __syncthreads();
+    constexpr int W = M > 64 ? M - 64 : 1;                                  // rays of a chunk that wait in LDS
+    volatile float *wl = reinterpret_cast<volatile float *>(smem + list_off) + (size_t) wave * W * 7;
+    uint16_t *stack = reinterpret_cast<uint16_t *>(smem + li.stack_off) + tid;
+    const uint32_t DONE = 0x10000u, IDLE = 0x20000u;
+    const uint32_t n_chunks = (n + M - 1) / M;
+    for (uint32_t chunk = blockIdx.x * 16u + wave; chunk < n_chunks; chunk += gridDim.x * 16u) {
+        const uint32_t base = chunk * M, cnt = min((uint32_t) M, n - base);
+        for (uint32_t k = lane; k + 64u < cnt; k += 64u) {
+            const uint32_t i = base + 64u + k;
+            wl[0 * W + k] = ox[i]; wl[1 * W + k] = oy[i]; wl[2 * W + k] = oz[i]; wl[3 * W + k] = dx[i]; wl[4 * W + k] = dy[i]; wl[5 * W + k] = dz[i]; wl[6 * W + k] = tmax[i];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        uint32_t my = base + lane, next = 64u, cur = lane < cnt ? 0u : IDLE;
+        V3 o(0.f), d(0.f); float maxt = 0.f;
+        if (lane < cnt) { o = V3(ox[my], oy[my], oz[my]); d = V3(dx[my], dy[my], dz[my]); maxt = tmax[my]; }
+        Hit best; best.t = kInf; best.u = best.v = 0.f; best.prim = 0xffffffffu;
+        float ix = slab_rcp(d.x), iy = slab_rcp(d.y), iz = slab_rcp(d.z);
+        float oxx = -o.x * ix, oyy = -o.y * iy, ozz = -o.z * iz;
+        int sp = 0;
+        for (;;) {
+            while (cur < 0x8000u) {
+                const f32x2 vix = { ix, ix }, viy = { iy, iy }, viz = { iz, iz }, vox = { oxx, oxx }, voy = { oyy, oyy }, voz = { ozz, ozz };
+                const float4 *nd = L.nodes + 4 * cur;
+                float4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3];
+                float limit = fmin_(best.t, maxt);
+                const f32x2 vax = pk_fma(f32x2{ n0.x, n0.y }, vix, vox), vay = pk_fma(f32x2{ n0.z, n0.w }, viy, voy), vaz = pk_fma(f32x2{ n2.x, n2.y }, viz, voz);
+                const f32x2 vbx = pk_fma(f32x2{ n1.x, n1.y }, vix, vox), vby = pk_fma(f32x2{ n1.z, n1.w }, viy, voy), vbz = pk_fma(f32x2{ n2.z, n2.w }, viz, voz);
+                float tmin0 = fmax_(fmax_(fmin_(vax.x, vax.y), fmin_(vay.x, vay.y)), fmax_(fmin_(vaz.x, vaz.y), 0.f));
+                float tmax0 = fmin_(fmin_(fmax_(vax.x, vax.y), fmax_(vay.x, vay.y)), fmin_(fmax_(vaz.x, vaz.y), limit));
+                float tmin1 = fmax_(fmax_(fmin_(vbx.x, vbx.y), fmin_(vby.x, vby.y)), fmax_(fmin_(vbz.x, vbz.y), 0.f));
+                float tmax1 = fmin_(fmin_(fmax_(vbx.x, vbx.y), fmax_(vby.x, vby.y)), fmin_(fmax_(vbz.x, vbz.y), limit));
+                bool h0 = tmin0 <= tmax0 * 1.000002f + 1e-30f, h1 = tmin1 <= tmax1 * 1.000002f + 1e-30f;
+                const uint32_t c0 = f2u(n3.x), c1 = f2u(n3.y);
+                if (h0 && h1) { bool swap = tmin1 < tmin0; stack[sp * 1024] = (uint16_t) (swap ? c0 : c1); ++sp; cur = swap ? c1 : c0; }
+                else if (h0 || h1) cur = h0 ? c0 : c1;
+                else if (sp == 0) cur = DONE;
+                else { --sp; cur = stack[sp * 1024]; }
+            }
+            if (cur < DONE) {
+                uint32_t slot = cur & 0x7fffu, last;
+                do { const uint2 ixw = L.tris[slot]; last = (ixw.y >> 16) & 1u; test_tri_lds(L, ixw, slot, o, d, maxt, best); ++slot; } while (!last);
+                if (sp == 0) cur = DONE; else { --sp; cur = stack[sp * 1024]; }
+            }
+            const bool fin = cur == DONE;
+            const unsigned long long fm = __ballot(fin);
+            if (fm) {
+                if (fin) {
+                    t[my] = best.t; u[my] = best.u; v[my] = best.v; prim[my] = best.prim != 0xffffffffu ? (best.prim & 0x7fffu) : 0xffffffffu;
+                    const uint32_t k = next + (uint32_t) __popcll(fm & ((1ull << lane) - 1ull));
+                    if (M > 64 && k < cnt) {
+                        const uint32_t w = k - 64u;
+                        o = V3(wl[0 * W + w], wl[1 * W + w], wl[2 * W + w]); d = V3(wl[3 * W + w], wl[4 * W + w], wl[5 * W + w]); maxt = wl[6 * W + w];
+                        my = base + k; cur = 0u; sp = 0;
+                        best.t = kInf; best.u = best.v = 0.f; best.prim = 0xffffffffu;
+                        ix = slab_rcp(d.x); iy = slab_rcp(d.y); iz = slab_rcp(d.z); oxx = -o.x * ix; oyy = -o.y * iy; ozz = -o.z * iz;
+                    } else cur = IDLE;
+                }
+                next += (uint32_t) __popcll(fm);
+            }
+            if (__ballot(cur != IDLE) == 0ull) break;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+#endif
+
 } // namespace lrt
