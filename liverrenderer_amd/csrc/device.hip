@@ -559,6 +559,7 @@ static DRenderParams make_params(const lrt_scene_desc &d, const ResolvedOpts &O,
     rp.profile = getenv("LRT_DEBUG_LAUNCH") ? 1u : 0u;                 // bit 0: per-tile-kind timing, results unchanged
 #ifdef LRT_EXPERIMENT
     if (getenv("LRT_EXP")) rp.profile |= (uint32_t) atoi(getenv("LRT_EXP"));   // cost-attribution switches (`make exp` build only)
+    if (getenv("LRT_PRB_DEBUG_LANE")) rp.pad1 = (uint32_t) atoi(getenv("LRT_PRB_DEBUG_LANE")) + 1u;   // per-trip printf of one lane's PRB passes
 #endif
     rp.seed_value = d.sampler_seed + O.seed; rp.base_seed = d.sampler_seed; rp.seed = O.seed;
     rp.ld_count = d.sampler_type == LRT_SAMPLER_LD ? O.spp_total : 0u; rp.pass_index = O.pass; rp.spp_total = O.spp_total; rp.tile_rank = O.tile_rank; rp.tile_count = O.tile_count; rp.n_lanes = n_lanes;

@@ -235,6 +235,7 @@ DEV V3 fma3(V3 a, float s, V3 b) { return V3(fma_(a.x, s, b.x), fma_(a.y, s, b.y
 DEV float max3(V3 a) { return fmax_(fmax_(a.x, a.y), a.z); }
 DEV V3 abs3(V3 a) { return V3(__builtin_fabsf(a.x), __builtin_fabsf(a.y), __builtin_fabsf(a.z)); }
 DEV bool any_nonzero(V3 a) { return a.x != 0.f || a.y != 0.f || a.z != 0.f; }
+DEV bool finite3(V3 a) { return (f2u(a.x) & 0x7f800000u) != 0x7f800000u && (f2u(a.y) & 0x7f800000u) != 0x7f800000u && (f2u(a.z) & 0x7f800000u) != 0x7f800000u; }
 DEV float mean3(V3 a) { return (a.x + a.y + a.z) * (1.f / 3.f); }
 DEV float luminance(V3 c) { return c.x * 0.212671f + c.y * 0.715160f + c.z * 0.072169f; }
 DEV float idx3(V3 v, uint32_t c) { return c == 0 ? v.x : (c == 1 ? v.y : v.z); }

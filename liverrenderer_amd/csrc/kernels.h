@@ -209,12 +209,12 @@ DEV void finish_path(SceneRef sc, RpRef rp, float *__restrict__ film, float *__r
     for (int ys = 0; ys < count; ++ys) {
         int y = piy - F.crop_offset_y + ys;
         float wy = rfilter_eval(F, rely + (float) ys);
-        if (y < 0 || y >= F.height || wy == 0.f) continue;
+        if (y < 0 || y >= F.height || (wy == 0.f && finite3(L))) continue;
         for (int xs = 0; xs < count; ++xs) {
             int x = pix - F.crop_offset_x + xs;
             if (x < 0 || x >= F.width) continue;
             float w = wy * rfilter_eval(F, relx + (float) xs);
-            if (w == 0.f) continue;
+            if (w == 0.f && finite3(L)) continue;                  // a zero weight adds nothing unless the radiance is non-finite (value * 0 = NaN, as imageblock.cpp computes it)
             splat(film + ((size_t) y * F.width + x) * C, w);
         }
     }
@@ -929,13 +929,14 @@ k_splat_lanes(ScenePtr scp, LaunchPtr lp) {
             const float wy = mine ? rfilter_eval(F, rely + (float) ys) : 0.f;
             for (int xs = 0; xs < count; ++xs, ++ci) {
                 const float w = mine ? wy * rfilter_eval(F, relx + (float) xs) : 0.f;
-                float r = L.x * w, g = L.y * w, b = L.z * w, a = alpha * w, ww = w;
+                // lanes outside the group add exact zeros (a product with their weight 0 would turn a non-finite radiance into NaN for this group's pixels)
+                float r = mine ? L.x * w : 0.f, g = mine ? L.y * w : 0.f, b = mine ? L.z * w : 0.f, a = alpha * w, ww = w;
                 if (!WEIGHTS_ONLY) { r = wave_sum(r); g = wave_sum(g); b = wave_sum(b); if (F.has_alpha) a = wave_sum(a); }
                 ww = wave_sum(ww);
                 if ((int) me == (ci & 63)) { tr = r; tg = g; tb = b; ta = a; tw = ww; }
                 if ((ci & 63) == 63 || ci == n_cells - 1) {            // a chunk of (up to) 64 cells is complete: lane c flushes cell base + c
                     const int cell = (ci & ~63) + (int) me;            // (footprints wider than 8 x 8 pixels take several chunks: gaussian stddev > 0.875, tent radius > 3.5)
-                    if (cell <= ci && tw != 0.f) {
+                    if (cell <= ci && (tw != 0.f || tr != tr || tg != tg || tb != tb)) {   // zero-weight cells only matter when a non-finite radiance made them NaN (imageblock.cpp adds value * 0 there)
                         const int cy = cell / count, cx = cell - cy * count;
                         const int x = gx - F.crop_offset_x + cx, y = gy - F.crop_offset_y + cy;
                         if (x >= 0 && x < F.width && y >= 0 && y < F.height) {

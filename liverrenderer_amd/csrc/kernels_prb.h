@@ -137,6 +137,9 @@ DEV bool prb_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, const TR &
             gs += dl * Lo * dws * M.scale;
             if (act_medium_scatter) ga += dl * Lo * (w / al);
         };
+#ifdef LRT_EXPERIMENT
+        if (rp.pad1 && s.lane == rp.pad1 - 1u) printf("  [dev] medium term: depth %u seg_t %.9g w %.9g %.9g %.9g L %.9g %.9g %.9g dl %.9g scatter %d\n", depth, seg_t, weight.x, weight.y, weight.z, L.x, L.y, L.z, delta_L.x, (int) act_medium_scatter);
+#endif
         term(weight.x, L.x, delta_L.x, M.sigma_t[0], M.albedo[0], G.sigma_t[0], G.albedo[0]);
         term(weight.y, L.y, delta_L.y, M.sigma_t[1], M.albedo[1], G.sigma_t[1], G.albedo[1]);
         term(weight.z, L.z, delta_L.z, M.sigma_t[2], M.albedo[2], G.sigma_t[2], G.albedo[2]);
@@ -164,6 +167,9 @@ DEV bool prb_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, const TR &
             V3 emitted = emitter_eval(sc, emitter, si);
             V3 contrib = count_direct ? throughput * emitted : throughput * mis_weight(s.last_pdf, emitter_pdf) * emitted;
             L = ADJOINT ? L - contrib : L + contrib;
+#ifdef LRT_EXPERIMENT
+            if (rp.pad1 && s.lane == rp.pad1 - 1u) printf("  [dev] %s emitter hit: depth %u contrib %.9g %.9g %.9g L after %.9g %.9g %.9g\n", ADJOINT ? "adjoint" : "primal", depth, contrib.x, contrib.y, contrib.z, L.x, L.y, L.z);
+#endif
         }
     }
     active_surface = active_surface && si.valid;
@@ -183,6 +189,9 @@ DEV bool prb_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, const TR &
         else { float pv = phase_eval(tab(sc.media, medium), mei.wi, ds.d); nee_weight = V3(pv); nee_pdf = pv; }
         V3 contrib = throughput * nee_weight * mis_weight(ds.pdf, ds.delta ? 0.f : nee_pdf) * emitted;
         L = ADJOINT ? L - contrib : L + contrib;
+#ifdef LRT_EXPERIMENT
+        if (rp.pad1 && s.lane == rp.pad1 - 1u) printf("  [dev] %s nee: depth %u surface %d contrib %.9g %.9g %.9g L after %.9g %.9g %.9g seg_sum %.9g %.9g %.9g\n", ADJOINT ? "adjoint" : "primal", depth, (int) active_e_surface, contrib.x, contrib.y, contrib.z, L.x, L.y, L.z, seg_sum.x, seg_sum.y, seg_sum.z);
+#endif
         if (ADJOINT) {
             G.sigma_t[0] += delta_L.x * contrib.x * seg_sum.x; G.sigma_t[1] += delta_L.y * contrib.y * seg_sum.y; G.sigma_t[2] += delta_L.z * contrib.z * seg_sum.z;
             if (active_e_medium && tab(sc.media, medium).phase == LRT_PHASE_HG && (gm < 0 || medium == gm))

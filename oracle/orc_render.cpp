@@ -911,6 +911,8 @@ static void path_sample(Ctx &C, Ray ray, V3 *out, bool *out_valid) {
 #include "orc_mis.h"
 
 /* --------------------------------------------------- PRB (prbvolpath.py) */
+/* ORC_PRB_DEBUG=1: per-trip terms of the adjoint on stderr (scripts/dbg/prb_lane_debug.py prints the device's beside them) */
+static const bool g_prb_debug = getenv("ORC_PRB_DEBUG") != nullptr;
 /* Gradient accumulators of one lane: d/d sigma_t[3] (w.r.t. the `sigma_t` property, i.e. before `scale`),
    d/d albedo[3], d/d g of medium 0..: the reference differentiates whatever parameters have gradients
    enabled; the oracle differentiates every medium's parameters into ONE set (scenes in scope have one medium). */
@@ -966,6 +968,7 @@ static V3 prb_sample_emitter(Ctx &C, V3 ref_p, V3 ref_n, const SI *ref_si, int m
             const lrt_medium_desc &M = S.media[medium];
             float c[3] = { tr_multiplier.x, tr_multiplier.y, tr_multiplier.z }, dl[3] = { delta_L.x, delta_L.y, delta_L.z }, ae[3] = { adj_emitted.x, adj_emitted.y, adj_emitted.z };
             for (int k = 0; k < 3; ++k) if (c[k] > 0.f) G->sigma_t[k] += (double) (dl[k] * ae[k] * (-seg_t) * M.scale);
+            if (g_prb_debug) fprintf(stderr, "  [orc] nee seg_t %.9g tr %.9g %.9g %.9g ae %.9g %.9g %.9g\n", seg_t, c[0], c[1], c[2], ae[0], ae[1], ae[2]);
         }
         transmittance *= tr_multiplier;
         if (active_surface) ray = spawn_ray(si.p, si.n, ray.d);
@@ -1036,6 +1039,7 @@ static void prb_sample(Ctx &C, Ray ray, bool adjoint, V3 delta_L, V3 L_in, V3 *L
                 if (!(seg_t < kInf)) dws = 0.f;                                     /* exp(-inf) = 0: no dependence */
                 G->sigma_t[k] += (double) (dl[k] * Lo * dws * M.scale);
                 if (act_medium_scatter) G->albedo[k] += (double) (dl[k] * Lo * (w[k] / M.albedo[k]));
+                if (g_prb_debug) fprintf(stderr, "  [orc] trip %u k %d seg_t %.9g w %.9g L %.9g dl %.9g scatter %d term %.9g\n", depth, k, seg_t, w[k], l[k], dl[k], (int) act_medium_scatter, dl[k] * Lo * dws * M.scale);
             }
         }
         /* ---- surface interactions */
@@ -1061,6 +1065,7 @@ static void prb_sample(Ctx &C, Ray ray, bool adjoint, V3 delta_L, V3 L_in, V3 *L
                 V3 emitted = emitter_eval(S, emitter, si);
                 V3 contrib = count_direct ? throughput * emitted : throughput * mis_weight(last_scatter_direction_pdf, emitter_pdf) * emitted;
                 L = adjoint ? L - contrib : L + contrib;
+                if (g_prb_debug && (delta_L.x != 0.f || !adjoint)) fprintf(stderr, "  [orc] %s emitter hit: depth %u contrib %.9g %.9g %.9g L after %.9g %.9g %.9g\n", adjoint ? "adjoint" : "primal", depth, contrib.x, contrib.y, contrib.z, L.x, L.y, L.z);
             }
         }
         active_surface = active_surface && si.valid;
@@ -1081,6 +1086,7 @@ static void prb_sample(Ctx &C, Ray ray, bool adjoint, V3 delta_L, V3 L_in, V3 *L
             else { float pv = phase_eval(S.media[medium], mei.wi, ds.d); nee_weight = V3(pv); nee_pdf = pv; }
             V3 contrib = throughput * nee_weight * mis_weight(ds.pdf, ds.delta ? 0.f : nee_pdf) * emitted;
             L = adjoint ? L - contrib : L + contrib;
+            if (g_prb_debug && (delta_L.x != 0.f || !adjoint)) fprintf(stderr, "  [orc] %s nee: depth %u surface %d contrib %.9g %.9g %.9g L after %.9g %.9g %.9g\n", adjoint ? "adjoint" : "primal", depth, (int) active_e_surface, contrib.x, contrib.y, contrib.z, L.x, L.y, L.z);
             if (adjoint) {
                 Sampler saved = C.smp; uint64_t ns = C.n_shadow, nn = C.n_shadow_needed;
                 C.smp = nee_rng;
@@ -1465,7 +1471,10 @@ extern "C" int orc_render_backward(orc_scene *s, const lrt_render_opts *opts, in
         float posx = (float) ((int) px + F.crop_offset_x), posy = (float) ((int) py + F.crop_offset_y);
         float jx, jy; C.next2(&jx, &jy);
         *spx = posx + jx; *spy = posy + jy;
-        *ray = sample_ray(S, fmaf(*spx, 1.f / (float) W, -(float) F.crop_offset_x / (float) W), fmaf(*spy, 1.f / (float) H, -(float) F.crop_offset_y / (float) H));
+        /* common.py sample_rays: scale = rcp(crop_size), offset = -crop_offset * scale, pos_adjusted = fma(pos_f, scale, offset): the
+           same arithmetic as render_sample (render_lane above); a division for the offset differs in the last bit under a crop window */
+        const float sclx = 1.f / (float) W, scly = 1.f / (float) H;
+        *ray = sample_ray(S, fmaf(*spx, sclx, -(float) F.crop_offset_x * sclx), fmaf(*spy, scly, -(float) F.crop_offset_y * scly));
     };
     /* weight film (sum of filter weights per pixel); box filter: exactly spp */
     std::vector<float> wfilm(np, box ? (float) O.spp : 0.f);

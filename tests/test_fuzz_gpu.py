@@ -188,7 +188,8 @@ def random_scene_xml_r2(seed, tmpdir):
     return xml, integrator
 
 
-@pytest.mark.parametrize("seed", range(24))
+# 20540: a multi-pass tent-filter biovolpath render whose lanes overflow (non-finite film values: same pattern on both sides)
+@pytest.mark.parametrize("seed", list(range(24)) + [20540])
 def test_random_scene_r2_bit_exact(mi, orc, tmp_path, seed):
     xml, integrator = random_scene_xml_r2(seed, tmp_path)
     sc = mi.load_string(xml)
@@ -201,7 +202,9 @@ def test_random_scene_r2_bit_exact(mi, orc, tmp_path, seed):
         assert film_close(raw, o.render(return_raw=True, seed=seed)[1]).all()
 
 
-@pytest.mark.parametrize("seed", range(24))
+# 20059, 21481: adjoint under a crop window (the oracle's ray set-up once differed from the forward pass in the last bit there);
+# 20756: a multi-pass tent-filter render with non-finite lanes (their zero-weight products must stay inside their own footprint)
+@pytest.mark.parametrize("seed", list(range(24)) + [20059, 21481, 20756])
 def test_random_scene_bit_exact(mi, orc, seed):
     xml, integrator = random_scene_xml(seed)
     sc = mi.load_string(xml)

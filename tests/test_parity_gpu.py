@@ -187,8 +187,15 @@ def test_furnace_on_gpu(mi):
 # ------------------------------------------------------------------------- film
 def film_close(g, c, weight_channel=-1, rtol=1e-5):
     """Float atomics reorder the per-pixel sums: compare relative to the pixel's accumulated weight."""
-    scale = np.maximum(np.abs(c).max(axis=-1, keepdims=True), 1.0)
-    return np.abs(g - c) <= rtol * scale * 8
+    fin = np.isfinite(c)
+    if fin.all() and np.isfinite(g).all():
+        scale = np.maximum(np.abs(c).max(axis=-1, keepdims=True), 1.0)
+        return np.abs(g - c) <= rtol * scale * 8
+    # a lane with a non-finite radiance (overflowing throughput in extreme random scenes) makes film values inf / NaN: the same values must be
+    # non-finite on both sides (value * weight as imageblock.cpp computes it, zero weights included); the finite ones compare as usual
+    with np.errstate(invalid="ignore"):
+        scale = np.maximum(np.where(fin, np.abs(c), 0.0).max(axis=-1, keepdims=True), 1.0)
+        return np.where(fin, np.abs(g - c) <= rtol * scale * 8, ~np.isfinite(g))
 
 
 @pytest.mark.parametrize("kw", [dict(spp=16), dict(spp=5, seed=4), dict(spp=16, integrator="volpath")])
