@@ -1348,8 +1348,8 @@ extern "C" int orc_render_scalar(orc_scene *s, const lrt_render_opts *opts, int 
                 for (uint32_t k = 0; k < O.spp; ++k) {
                     float jx = Cx.next(), jy = Cx.next();
                     float spx = posx + jx, spy = posy + jy;
-                    Ray ray = sample_ray(S, fmaf(spx, 1.f / (float) W, -(float) F.crop_offset_x / (float) W),
-                                         fmaf(spy, 1.f / (float) H, -(float) F.crop_offset_y / (float) H));
+                    const float sclx = 1.f / (float) W, scly = 1.f / (float) H;       /* integrator.cpp:462-466: scale = 1 / crop_size, offset = -crop_offset * scale, adjusted_pos = fmadd(sample_pos, scale, offset) */
+                    Ray ray = sample_ray(S, fmaf(spx, sclx, -(float) F.crop_offset_x * sclx), fmaf(spy, scly, -(float) F.crop_offset_y * scly));
                     V3 L; bool valid;
                     if (O.integrator == LRT_INTEGRATOR_PATH) path_sample(Cx, ray, &L, &valid);
                     else if (O.integrator == LRT_INTEGRATOR_BIOVOLPATH) biovolpath_sample(Cx, ray, S.d.sensor.medium, &L, &valid);
