@@ -246,7 +246,10 @@ LRT_API void       lrt_scene_free(lrt_scene *scene);
 
 /* film_raw: crop_h * crop_w * C floats (C = 5 if has_alpha else 4: R,G,B,[A],W),
  * image:    crop_h * crop_w * (4 if has_alpha else 3) developed floats.
- * Either may be NULL.  */
+ * Either may be NULL.  Both are overwritten: the film is cleared before the samples are accumulated (ImageBlock::clear, as
+ * Film::prepare / SamplingIntegrator::render do before a render); with opts->output_on_device the two pointers are device
+ * memory and the call returns after the library's stream has finished with them.  A tile shard (tile_count > 1) fills only
+ * its own tiles' samples into the full-size film: shard films add up to the unsharded film.  */
 LRT_API lrt_status lrt_render(lrt_scene *scene, const lrt_render_opts *opts,
                               float *film_raw, float *image);
 LRT_API lrt_status lrt_render_stats_get(const lrt_scene *scene, lrt_render_stats *out);
