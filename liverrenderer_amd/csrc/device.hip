@@ -203,6 +203,17 @@ static void upload_media(DeviceScene *D, const lrt_scene_desc &d) {
         for (int k = 0; k < 3; ++k) { o.sigma_t[k] = M.sigma_t[k] * M.scale; o.albedo[k] = M.albedo[k]; }   // homogeneous.cpp:121-126 eval_sigmat
         o.has_spectral_extinction = M.has_spectral_extinction; o.sample_emitters = M.sample_emitters; o.phase = M.phase; o.g = M.g;
         o.scale = M.scale; o.het = M.type == LRT_MEDIUM_HETEROGENEOUS ? 1 : 0;
+        // Early NEE rejection (volpath_iteration): an infinite emitter's sample lies at distance >= 2 r (r: the scene's bounding sphere); the
+        // kernel rejects when -log(1 - u) / sigma_t <= bound(dist), bound(x) = x * 0.998f - 1e-3f (monotone in x).  1 - u >= vmin implies that
+        // for dist = 2 r, hence for every sample: vmin = exp(-sigma_t bound(2 r) (1 - 1e-4)) (1 + 1e-4), far outside the 3e-7 relative error
+        // of the kernels' logarithm and the rounding of the division; 2 (never true) when sigma_t bound is too small for the margin to mean anything.
+        const float bound = (2.f * D->sc.env.bsphere_r) * 0.998f - 1e-3f;
+        for (int k = 0; k < 3; ++k) {
+            const double x = (double) o.sigma_t[k] * (double) bound;
+            double v = (x > 0.05 && std::isfinite(x)) ? std::exp(-x * (1.0 - 1e-4)) * (1.0 + 1e-4) : 2.0;
+            float vf = (float) v; if ((double) vf < v) vf = std::nextafter(vf, 3.f);
+            o.nee_vmin[k] = vf;
+        }
     }
     D->h_het.assign(std::max<uint32_t>(d.n_media, 1), DHetMedium{});
     for (uint32_t i = 0; i < d.n_media; ++i) {
@@ -291,6 +302,9 @@ DeviceScene *device_scene_create(const lrt_scene_desc &d, int device) {
             D->lds.blob_bytes = (uint32_t) blob.size(); D->lds.nodes_off = 0; D->lds.verts_off = (uint32_t) nodes_b; D->lds.tris_off = (uint32_t) (nodes_b + verts_b);
             D->lds.stack_off = (uint32_t) blob.size(); D->lds.total_bytes = (uint32_t) total;
             #define LRT_SMEM(K) HIP_CHECK(hipFuncSetAttribute((const void *) K, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_limit))
+#ifdef LRT_DEV_VOLPATH_ONLY                 // developer build (make dev): only the independent-sampler volpath kernel with the LDS BVH is compiled
+            LRT_SMEM((k_render<LRT_INTEGRATOR_VOLPATH, 1024, true, false>)); LRT_SMEM((k_trace_lds<true>)); LRT_SMEM((k_trace_lds<false>));
+#else
             LRT_SMEM((k_render<LRT_INTEGRATOR_PATH, 1024, true, false>)); LRT_SMEM((k_render<LRT_INTEGRATOR_VOLPATH, 1024, true, false>));
             LRT_SMEM((k_render<LRT_INTEGRATOR_PATH, 1024, true, true>)); LRT_SMEM((k_render<LRT_INTEGRATOR_VOLPATH, 1024, true, true>));
             LRT_SMEM((k_render<LRT_INTEGRATOR_BIOVOLPATH, 1024, true, false>)); LRT_SMEM((k_render<LRT_INTEGRATOR_BIOVOLPATH, 1024, true, true>));
@@ -301,6 +315,7 @@ DeviceScene *device_scene_create(const lrt_scene_desc &d, int device) {
             LRT_SMEM((k_render_prb<false, 1024, true, false>)); LRT_SMEM((k_render_prb<true, 1024, true, false>));
             LRT_SMEM((k_render_prb<false, 1024, true, true>)); LRT_SMEM((k_render_prb<true, 1024, true, true>));
             LRT_SMEM((k_trace_lds<true>)); LRT_SMEM((k_trace_lds<false>));
+#endif
             #undef LRT_SMEM
             D->use_lds = true;
         }
@@ -375,6 +390,18 @@ DeviceScene *device_scene_create(const lrt_scene_desc &d, int device) {
         if (B.type == LRT_BSDF_NULL) sc.has_null_bsdf = 1;
     }
     sc.bsdfs = D->track(dev_upload(bsdfs.data(), bsdfs.size(), st));
+    // ---- bounds (src/render/scene.cpp:49; include/mitsuba/core/bbox.h:343-346; envmap.cpp:337-351)
+    DEnv &E = sc.env; memset(&E, 0, sizeof(E)); E.type = -1; E.emitter = -1;
+    {
+        float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
+        for (uint32_t i = 0; i < d.n_vertices; ++i) for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], d.positions[3 * i + a]); hi[a] = fmaxf(hi[a], d.positions[3 * i + a]); }
+        const float ray_eps = 5.9604644775390625e-8f * 1500.f;
+        if (d.n_vertices) {
+            float c[3], dd[3]; for (int a = 0; a < 3; ++a) { c[a] = (hi[a] + lo[a]) * 0.5f; dd[a] = c[a] - hi[a]; E.bsphere_c[a] = c[a]; }
+            float r = sqrtf(fmaf(dd[2], dd[2], fmaf(dd[1], dd[1], dd[0] * dd[0])));
+            E.bsphere_r = fmaxf(ray_eps, r * (1.f + ray_eps));
+        } else { E.bsphere_c[0] = E.bsphere_c[1] = E.bsphere_c[2] = 0.f; E.bsphere_r = ray_eps; }
+    }
     // ---- media
     HIP_CHECK(hipMalloc((void **) &D->d_media, std::max<uint32_t>(d.n_media, 1) * sizeof(DMedium))); D->track(D->d_media);
     HIP_CHECK(hipMalloc((void **) &D->d_bio, std::max<uint32_t>(d.n_media, 1) * sizeof(DBioMedium))); D->track(D->d_bio);
@@ -390,18 +417,6 @@ DeviceScene *device_scene_create(const lrt_scene_desc &d, int device) {
         D->has_het = true;
     }
     upload_media(D.get(), d); sc.media = D->d_media; sc.bio = D->d_bio; sc.het = D->d_het;
-    // ---- bounds (src/render/scene.cpp:49; include/mitsuba/core/bbox.h:343-346; envmap.cpp:337-351)
-    DEnv &E = sc.env; memset(&E, 0, sizeof(E)); E.type = -1; E.emitter = -1;
-    {
-        float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
-        for (uint32_t i = 0; i < d.n_vertices; ++i) for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], d.positions[3 * i + a]); hi[a] = fmaxf(hi[a], d.positions[3 * i + a]); }
-        const float ray_eps = 5.9604644775390625e-8f * 1500.f;
-        if (d.n_vertices) {
-            float c[3], dd[3]; for (int a = 0; a < 3; ++a) { c[a] = (hi[a] + lo[a]) * 0.5f; dd[a] = c[a] - hi[a]; E.bsphere_c[a] = c[a]; }
-            float r = sqrtf(fmaf(dd[2], dd[2], fmaf(dd[1], dd[1], dd[0] * dd[0])));
-            E.bsphere_r = fmaxf(ray_eps, r * (1.f + ray_eps));
-        } else { E.bsphere_c[0] = E.bsphere_c[1] = E.bsphere_c[2] = 0.f; E.bsphere_r = ray_eps; }
-    }
     // ---- emitters
     std::vector<DEmitter> em(d.n_emitters); std::vector<float> env_rgbx, hier; bool env_interior_positive = false;
     for (uint32_t i = 0; i < d.n_emitters; ++i) {
@@ -632,10 +647,14 @@ static void launch_prb(DeviceScene *D, const DRenderParams &rp, const PoolGeomet
     a.pixel_list = pixel_list; a.lane_begin = lane_begin; a.n = rp.n_lanes; a.L_buf = L_buf; a.grad_image = grad_image; a.wfilm = D->wfilm; a.grads = grads;
     a.film = film; a.sample_out = sample_out; a.sample_base = lane_begin;
     const LaunchPtr lp = push_launch(D, a);
+#ifdef LRT_DEV_VOLPATH_ONLY
+    (void) lp; throw std::runtime_error("developer build: volpath only");
+#else
     #define LRT_LAUNCH_PRB(BS, LDSB, LD) k_render_prb<ADJOINT, BS, LDSB, LD><<<g.n_wg, BS, g.smem, st>>>((ScenePtr) D->d_sc, lp)
     if (D->use_lds) { if (rp.ld_count) LRT_LAUNCH_PRB(1024, true, true); else LRT_LAUNCH_PRB(1024, true, false); }
     else { if (rp.ld_count) LRT_LAUNCH_PRB(LRT_BLOCK, false, true); else LRT_LAUNCH_PRB(LRT_BLOCK, false, false); }
     #undef LRT_LAUNCH_PRB
+#endif
     HIP_CHECK(hipGetLastError());
 }
 
@@ -677,6 +696,12 @@ static void run_wavefront(DeviceScene *D, const lrt_scene_desc &d, const Resolve
         DLaunch a{}; a.rp = rp; a.li = D->lds; a.q0 = D->q[0]; a.q1 = D->q[1]; a.P = g.P; a.cnt = D->counters; a.pixel_list = pixel_list;
         a.lane_begin = lane_begin; a.n = n_lanes; a.film = film; a.sample_out = sample_out; a.sample_base = lane_begin;
         const LaunchPtr lp = push_launch(D, a);
+#ifdef LRT_DEV_VOLPATH_ONLY
+        if (!(D->use_lds && O.integrator == LRT_INTEGRATOR_VOLPATH && !rp.ld_count && !D->has_het)) throw std::runtime_error("developer build: volpath / independent sampler / LDS BVH only");
+        k_render<LRT_INTEGRATOR_VOLPATH, 1024, true, false><<<g.n_wg, 1024, g.smem, st>>>((ScenePtr) D->d_sc, lp);
+        #define LRT_LAUNCH_I(BS, LDSB)
+        #define LRT_LAUNCH(I, BS, LDSB)
+#else
         #define LRT_LAUNCH(I, BS, LDSB) do { if (rp.ld_count) k_render<I, BS, LDSB, true><<<g.n_wg, BS, g.smem, st>>>((ScenePtr) D->d_sc, lp); \
                                              else k_render<I, BS, LDSB, false><<<g.n_wg, BS, g.smem, st>>>((ScenePtr) D->d_sc, lp); } while (0)
         #define LRT_LAUNCH_I(BS, LDSB) do { switch (O.integrator) { \
@@ -686,6 +711,7 @@ static void run_wavefront(DeviceScene *D, const lrt_scene_desc &d, const Resolve
             case LRT_INTEGRATOR_VOLPATHMIS: if (d.use_spectral_mis) LRT_LAUNCH(LRT_INTEGRATOR_VOLPATHMIS, BS, LDSB); else LRT_LAUNCH(LRT_INTEGRATOR_VOLPATHMIS_PLAIN, BS, LDSB); break; \
             default: if (D->has_het) LRT_LAUNCH(LRT_INTEGRATOR_VOLPATH_HET, BS, LDSB); else LRT_LAUNCH(LRT_INTEGRATOR_VOLPATH, BS, LDSB); } } while (0)
         if (D->use_lds) LRT_LAUNCH_I(1024, true); else LRT_LAUNCH_I(LRT_BLOCK, false);
+#endif
         #undef LRT_LAUNCH_I
         #undef LRT_LAUNCH
         HIP_CHECK(hipGetLastError());

@@ -30,7 +30,8 @@ struct DMedium {
     int32_t has_spectral_extinction, sample_emitters, phase; float g;
     float scale; int32_t het;            // sigma_t = property * scale (needed by the PRB adjoint); het: heterogeneous (sc.het[index])
     float w_spec[3], w_plain[3];         // real-scattering weights sigma_s / mean(sigma_t / combined), sigma_s / sigma_t (k_medium_prepare)
-    float pad2[2];
+    float nee_vmin[3];                   // per channel: 1 - u >= nee_vmin proves that the free-flight distance -log(1 - u) / sigma_t stays below the distance
+    float pad2[3];                       // of every sample of an infinite emitter (upload_media; volpath_iteration's early NEE rejection)
 };
 
 // bio media (liver / parenchyma / glissonCapsule): element coefficients of the 5-argument sample_interaction

@@ -27,22 +27,34 @@ struct PathState {
 // BIO: a queued path's ray always comes from spawn_ray (maxt = largest float), so its maxt slot carries si_t instead, and
 // the seventh stream holds tissueDepth and the element competition the look-ahead already ran (96 B records)
 // MODE: 0 path / volpath (88 B), 1 biovolpath* (96 B), 2 volpath with heterogeneous media (104 B), 3 volpathmis (168 B)
+// A record as the stream loads return it.  Fetching (the loads) and unpacking (the first use of their results) are apart so that the
+// render kernel can ask for a tile's records while the previous tile is still being compacted and stored.
+struct RawState { float4 a, b, c, d, e; uint2 r; float2 td; float4 hit, w1, w2, w3, w4; };
 template <int MODE = 0, typename QS>
-DEV void load_state(const QS &q, size_t i, PathState &s) {
-    float4 a = q.o_maxt[i], b = q.d_eta[i], c = q.tp_pdf[i], d = q.res_flags[i], e = q.lp_lane[i]; uint2 r = q.rng[i];
+DEV void fetch_state(const QS &q, size_t i, RawState &w) {
+    w.a = q.o_maxt[i]; w.b = q.d_eta[i]; w.c = q.tp_pdf[i]; w.d = q.res_flags[i]; w.e = q.lp_lane[i]; w.r = q.rng[i];
+    if (MODE == 1) w.td = q.tdepth[i];
+    if (MODE == 2 || MODE == 3) w.hit = q.hit[i];
+    if (MODE == 3) { w.w1 = q.w1[i]; w.w2 = q.w2[i]; w.w3 = q.w3[i]; w.w4 = q.w4[i]; }
+}
+template <int MODE = 0>
+DEV void unpack_state(const RawState &w, PathState &s) {
+    const float4 a = w.a, b = w.b, c = w.c, d = w.d, e = w.e; const uint2 r = w.r;
     s.o = V3(a.x, a.y, a.z); s.maxt = a.w; s.d = V3(b.x, b.y, b.z); s.eta = b.w;
     s.tp = V3(c.x, c.y, c.z); s.last_pdf = c.w; s.res = V3(d.x, d.y, d.z); s.flags = f2u(d.w);
     s.lp = V3(e.x, e.y, e.z); s.lane = f2u(e.w); s.rng_state = ((uint64_t) r.y << 32) | r.x;
     if (MODE == 0) { s.ff_t = a.w; s.maxt = kLargest; }          // a queued ray always comes from spawn_ray: maxt = largest float
-    if (MODE == 1) { s.si_t = a.w; s.maxt = kLargest; const float2 td = q.tdepth[i]; s.tdepth = __builtin_fabsf(td.x); s.bio_hep = (f2u(td.x) >> 31) != 0u; s.bio_dist = td.y; }
-    if (MODE == 2 || MODE == 3) s.hit = q.hit[i];
+    if (MODE == 1) { s.si_t = a.w; s.maxt = kLargest; const float2 td = w.td; s.tdepth = __builtin_fabsf(td.x); s.bio_hep = (f2u(td.x) >> 31) != 0u; s.bio_dist = td.y; }
+    if (MODE == 2 || MODE == 3) s.hit = w.hit;
     if (MODE == 3) {
-        const float4 w1 = q.w1[i], w2 = q.w2[i], w3 = q.w3[i], w4 = q.w4[i];
+        const float4 w1 = w.w1, w2 = w.w2, w3 = w.w3, w4 = w.w4;
         float *W = &s.W[0][0][0];
         W[0] = c.x; W[1] = c.y; W[2] = c.z; W[3] = c.w; W[4] = w1.x; W[5] = w1.y; W[6] = w1.z; W[7] = w1.w; W[8] = w2.x;
         W[9] = w2.y; W[10] = w2.z; W[11] = w2.w; W[12] = w3.x; W[13] = w3.y; W[14] = w3.z; W[15] = w3.w; W[16] = w4.x; W[17] = w4.y;
     }
 }
+template <int MODE = 0, typename QS>
+DEV void load_state(const QS &q, size_t i, PathState &s) { RawState w; fetch_state<MODE>(q, i, w); unpack_state<MODE>(w, s); }
 template <int MODE = 0, typename QS>
 DEV void store_state(const QS &q, size_t i, const PathState &s) {
     q.o_maxt[i] = make_float4(s.o.x, s.o.y, s.o.z, MODE == 1 ? s.si_t : (MODE == 0 ? s.ff_t : s.maxt));
@@ -233,31 +245,17 @@ DEV void finish_paths_wave(SceneRef sc, RpRef rp, float *__restrict__ film, floa
     if (rp.integrator == LRT_INTEGRATOR_PATH && !valid) L = V3(0.f);
     uint32_t pixel = 0xffffffffu;
     if (finishing) { int px, py; lane_to_pixel(sc, rp, lane, &px, &py); pixel = (uint32_t) (py - F.crop_offset_y) * (uint32_t) F.width + (uint32_t) (px - F.crop_offset_x); }
-    float a = valid ? 1.f : 0.f;
     unsigned long long todo = __ballot(finishing);
     const uint32_t me = threadIdx.x & 63u;
-#ifdef LRT_EXPERIMENT
-    if (rp.profile & 2u) return;                    // cost attribution: no film atomics at all (RESULT-CHANGING, `make exp` only)
-    int rounds = 0;
-#endif
     while (todo) {
-#ifdef LRT_EXPERIMENT
-        if ((rp.profile & 4u) && rounds++ >= 2) {   // cost attribution: per-lane atomics after two leaders
-            if (finishing && ((todo >> me) & 1ull)) {
-                float *p = film + (size_t) pixel * F.channels;
-                atomicAdd(p + 0, L.x); atomicAdd(p + 1, L.y); atomicAdd(p + 2, L.z);
-                if (F.has_alpha) { atomicAdd(p + 3, a); atomicAdd(p + 4, 1.f); } else atomicAdd(p + 3, 1.f);
-            }
-            break;
-        }
-#endif
         int leader = __ffsll((long long) todo) - 1;
         uint32_t key = __shfl(pixel, leader);
         bool mine = finishing && pixel == key;
         unsigned long long grp = __ballot(mine);
-        float r = mine ? L.x : 0.f, g = mine ? L.y : 0.f, b = mine ? L.z : 0.f, al = mine ? a : 0.f, w = mine ? 1.f : 0.f;
-        r = wave_sum(r); g = wave_sum(g); b = wave_sum(b); w = wave_sum(w);
-        if (F.has_alpha) al = wave_sum(al);
+        float r = mine ? L.x : 0.f, g = mine ? L.y : 0.f, b = mine ? L.z : 0.f;
+        r = wave_sum(r); g = wave_sum(g); b = wave_sum(b);
+        // the weight and alpha sums are counts of lanes (sums of ones: exact in binary32): population counts on the scalar unit
+        const float w = (float) __popcll(grp), al = F.has_alpha ? (float) __popcll(__ballot(mine && valid)) : 0.f;
         if ((int) me == leader) {
             float *p = film + (size_t) key * F.channels;
             atomicAdd(p + 0, r); atomicAdd(p + 1, g); atomicAdd(p + 2, b);
@@ -344,10 +342,17 @@ DEV V3 volpath_sample_emitter(SceneRef sc, SMP &rng, V3 ref_p, V3 ref_n, bool re
 // Returns true when the path survives.
 // HET: the scene holds heterogeneous media (delta tracking, volpath.cpp:238-259): a null collision moves the ray origin
 // and keeps the surface interaction found earlier (`needs_intersection` stays false), which the record carries as a hit.
+// PRE (every kernel but the heterogeneous-media one): the first stage of a trip - the termination test (volpath.cpp:190-203) and, inside
+// a medium, the free-flight draw (:220, medium.cpp:40-82) - runs one trip early, at the end of the previous trip (`fresh`: at the start
+// of a camera lane's first trip), on the lane's own generator: same draws in the same order.  A queued record therefore holds a path
+// that is known to run its next trip, with the throughput already divided by the survival probability, the free-flight distance
+// in the record (ff_t) and, when the distance field proves that distance free of surfaces, PF_NOHIT.
 template <bool HET, typename SMP, typename TR>
-DEV bool volpath_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, const TR &tr, uint32_t &n_shadow, uint32_t &n_extra) {
+DEV bool volpath_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, const TR &tr, uint32_t &n_shadow, uint32_t &n_extra, bool fresh = false) {
+    constexpr bool PRE = !HET;
     uint32_t depth = s.flags & PF_DEPTH_MASK;
-    const bool proven_empty = (s.flags & PF_NOHIT) != 0;
+    bool proven_empty = (s.flags & PF_NOHIT) != 0;
+    float ff_t = s.ff_t;
     const bool needs_intersection = !(HET && (s.flags & PF_HAVE_SI));
     bool act_null_scatter = false;
     Hit hkeep; hkeep.t = s.hit.x; hkeep.u = s.hit.y; hkeep.v = s.hit.z; hkeep.prim = f2u(s.hit.w);
@@ -363,13 +368,27 @@ DEV bool volpath_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, const 
         s.flags = (depth & PF_DEPTH_MASK) | ((uint32_t) (medium + 1) << PF_MEDIUM_SHIFT) | (channel << PF_CHANNEL_SHIFT) |
                   (specular_chain ? PF_SPECULAR : 0u) | (valid_ray ? PF_VALID : 0u);
     };
-    // ---- termination (volpath.cpp:190-203)
-    bool active = any_nonzero(throughput);
-    float q = fmin_(max3(throughput) * sqr(eta), .95f);
-    bool perform_rr = depth > (uint32_t) rp.rr_depth;
-    if (active) { float u = rng.next(); active = (u < q) || !perform_rr; }
-    if (perform_rr) throughput = throughput * rcp(q);
-    active = active && depth < max_depth;
+    // ---- termination (volpath.cpp:190-203) of the trip about to run (PRE: called for the NEXT trip, see above)
+    auto termination_stage = [&]() -> bool {
+        bool a = any_nonzero(throughput);
+        const float q = fmin_(max3(throughput) * sqr(eta), .95f);
+        const bool perform_rr = depth > (uint32_t) rp.rr_depth;
+        if (a) { const float u = rng.next(); a = (u < q) || !perform_rr; }
+        if (perform_rr) throughput = throughput * rcp(q);
+        return a && depth < max_depth;
+    };
+    // PRE, inside a medium: the free-flight draw of the trip about to run, and the attempt to prove that distance free of surfaces
+    uint32_t nohit = 0;
+    float cache_t = u2f(0x7fc00000u);
+    auto free_flight_stage = [&]() {
+        if (medium < 0) return;
+        const DMedium M = tab(sc.media, medium);
+        cache_t = medium_sampled_t(M, rng.next(), channel);
+        if (sc.grid.enabled) { const MI m2 = medium_interaction_at(M, ray, cache_t); if (m2.valid() && segment_proven_empty(sc.grid, ray.o, ray.d, m2.t)) nohit = PF_NOHIT; }
+    };
+    bool active = true;
+    if (!PRE) active = termination_stage();
+    else if (fresh) { active = termination_stage(); if (active) { free_flight_stage(); ff_t = cache_t; proven_empty = nohit != 0; nohit = 0; cache_t = u2f(0x7fc00000u); } }
     if (!active) { commit(); return false; }
 
     bool active_medium = medium >= 0, active_surface = !active_medium;
@@ -380,16 +399,11 @@ DEV bool volpath_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, const 
     if (active_medium) {
         const DMedium M = tab(sc.media, medium);
         const bool het = HET && M.het;
-        const float sample = rng.next();
-        if (!HET && s.ff_t == s.ff_t) mei = medium_interaction_at(M, ray, s.ff_t);    // the previous trip's look-ahead drew this distance (same sample, channel, medium)
-        else mei = het ? het_sample_interaction(M, tab(sc.het, medium), ray, sample) : medium_sample_interaction(M, ray, sample, channel);
+        if (PRE) mei = medium_interaction_at(M, ray, ff_t);          // the free-flight stage drew this distance (same sample, channel, medium)
+        else { const float sample = rng.next(); mei = het ? het_sample_interaction(M, tab(sc.het, medium), ray, sample) : medium_sample_interaction(M, ray, sample, channel); }
         if (mei.valid() && !het) ray.maxt = mei.t;                              // medium->is_homogeneous() only (volpath.cpp:221)
         if (!needs_intersection) si = compute_si(sc, ray, hkeep);                // the interaction a null collision kept
         else if (!proven_empty) { hkeep = tr.closest(ray); si = tr.surface(sc, ray, hkeep); }   // else: no surface within mei.t (look-ahead of the previous trip)
-#ifdef LRT_EXPERIMENT
-        if (!proven_empty && (rp.profile & 0x10000u)) { Ray r2 = ray; r2.o.x += 1e-30f; Hit h = tr.closest(r2); if (h.t == -1.f) si.t = 0.f; }
-        if (!proven_empty && (rp.profile & 0x20000u)) { Ray r2 = ray; r2.o.x += 1e-30f; Hit h; h.prim = si.valid ? si.prim : 0xffffffffu; h.t = si.t; h.u = si.uv.x; h.v = si.uv.y; SI s2 = compute_si(sc, r2, h); if (s2.t == -1.f) si.t = 0.f; }
-#endif
         if (si.t < mei.t) mei.t = kInf;
         if (M.has_spectral_extinction) {
             float t = fmin_(mei.t, si.t) - mei.mint;
@@ -442,10 +456,14 @@ DEV bool volpath_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, const 
                 float u3 = rng.next();
                 const float lo = 9.5367431640625e-7f, hi = 1.f - 9.5367431640625e-7f;
                 bool interior = sc.env.type == LRT_EMITTER_CONSTANT || (sx > lo && sx < hi && sy > lo && sy < hi);
-                float sampled_t = 0.f + (-m_log(1.f - u3) / idx3(V3(M.sigma_t[0], M.sigma_t[1], M.sigma_t[2]), channel));
-                V3 cc(sc.env.bsphere_c[0], sc.env.bsphere_c[1], sc.env.bsphere_c[2]);
-                float dist = 2.f * fmax_(sc.env.bsphere_r, norm(mei.p - cc));
-                rejected = interior && sampled_t <= dist * 0.998f - 1e-3f;
+                // (the emitter sample is at least 2 r away: 1 - u3 >= nee_vmin decides the comparison below without the logarithm, upload_media)
+                rejected = interior;
+                if (!(1.f - u3 >= idx3(V3(M.nee_vmin[0], M.nee_vmin[1], M.nee_vmin[2]), channel))) {
+                    float sampled_t = 0.f + (-m_log(1.f - u3) / idx3(V3(M.sigma_t[0], M.sigma_t[1], M.sigma_t[2]), channel));
+                    V3 cc(sc.env.bsphere_c[0], sc.env.bsphere_c[1], sc.env.bsphere_c[2]);
+                    float dist = 2.f * fmax_(sc.env.bsphere_r, norm(mei.p - cc));
+                    rejected = interior && sampled_t <= dist * 0.998f - 1e-3f;
+                }
                 if (!rejected) rng = saved;
             }
             if (!rejected) {
@@ -522,22 +540,13 @@ DEV bool volpath_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, const 
         if (is_medium_transition(sd)) medium = target_medium(sd, ray.d, si.n);
     }
     active = active && (active_surface || active_medium);
-    // ---- look-ahead into the next trip (exact: same draws on a copy of the generator).  (1) A path the next trip's
-    // termination test (volpath.cpp:190-203) would stop is retired now; that trip is counted in n_extra.  (2) For a path
-    // inside a medium the next free-flight distance is known, so the distance field may already prove that the segment
-    // reaches no surface: such paths are queued separately and skip the ray query.
-    uint32_t nohit = 0;
-    float cache_t = u2f(0x7fc00000u);
-#ifdef LRT_EXPERIMENT
-    if (active && (rp.profile & 0x40000u) && medium >= 0 && sc.grid.enabled) {
-        SMP pk = rng; (void) pk.next();
-        const DMedium M = tab(sc.media, medium);
-        Ray r2 = ray; r2.o.x += 1e-30f;
-        MI m2 = medium_sample_interaction(M, r2, pk.next(), channel);
-        if (m2.valid() && segment_proven_empty(sc.grid, r2.o, r2.d, m2.t) && m2.t == -1.f) nohit = PF_NOHIT;
-    }
-#endif
-    if (active) {
+    // ---- the first stage of the next trip.  PRE: for real (see above): a path that stops there is retired now and that trip is counted
+    // in n_extra; inside a medium the next free-flight distance is then known and the distance field may prove that the segment
+    // reaches no surface: such paths are queued apart and skip their ray query.
+    // !PRE (heterogeneous media): the same as a look-ahead on a copy of the generator; only the retirement and the proof are kept.
+    if (PRE) {
+        if (active) { if (!termination_stage()) { active = false; n_extra += 1; } else free_flight_stage(); }
+    } else if (active) {
         SMP pk = rng;
         bool a2 = any_nonzero(throughput);
         float q2 = fmin_(max3(throughput) * sqr(eta), .95f);
@@ -550,7 +559,6 @@ DEV bool volpath_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, const 
                 const float t2 = medium_sampled_t(M, pk.next(), channel);
                 const MI m2 = medium_interaction_at(M, ray, t2);
                 if (m2.valid() && segment_proven_empty(sc.grid, ray.o, ray.d, m2.t)) nohit = PF_NOHIT;
-                cache_t = t2;
             }
         }
     }
@@ -682,8 +690,8 @@ DEV void retire_and_compact_wave(SceneRef sc, RpRef rp, bool had_path, bool aliv
                                  float *__restrict__ film, float *__restrict__ sample_out, uint64_t sample_base,
                                  const LRT_CONST DPathStreams &qout, size_t pool, uint32_t P, uint32_t *s_out /* LDS [3] */) {
     const uint32_t lane_in_wave = threadIdx.x & 63u;
-    finish_paths_wave(sc, rp, film, sample_out, sample_base, had_path && !alive, s.lane, s.res, (s.flags & PF_VALID) != 0);
-    if (rp.pass_out && had_path && !alive) rp.pass_out[lane_local_index(rp, s.lane)] = s.rng_state;       // next pass continues this stream
+    // survivors first: their stores are the oldest memory operations the next tile's record loads have to wait for (the loads reuse
+    // the registers the stores read), so they go out before the film sums, not after them
     const int region = !(s.flags & PF_MEDIUM_MASK) ? 2 : ((s.flags & PF_NOHIT) ? 0 : 1);
     const unsigned long long m0 = __ballot(alive && region == 0), m1 = __ballot(alive && region == 1), m2 = __ballot(alive && region == 2);
     uint32_t base = 0;
@@ -697,6 +705,8 @@ DEV void retire_and_compact_wave(SceneRef sc, RpRef rp, bool had_path, bool aliv
         const uint32_t slot = b + (uint32_t) __popcll(mine & ((1ull << lane_in_wave) - 1ull));
         store_state<MODE>(qout, pool + (region == 0 ? slot : (region == 1 ? P + slot : 2u * P - 1u - slot)), s);
     }
+    if (rp.pass_out && had_path && !alive) rp.pass_out[lane_local_index(rp, s.lane)] = s.rng_state;       // next pass continues this stream
+    finish_paths_wave(sc, rp, film, sample_out, sample_base, had_path && !alive, s.lane, s.res, (s.flags & PF_VALID) != 0);
 }
 
 // 4 waves per SIMD for every variant (128 VGPRs): one 1024-thread workgroup per CU, or four 256-thread ones
@@ -768,17 +778,6 @@ k_render(ScenePtr scp, LaunchPtr lp) {
                 had_path = i < fresh;
                 if (had_path) s = generate_camera_path<LD>(sc, rp, A.pixel_list, A.lane_begin + fresh_base + i);
             }
-#ifdef LRT_EXPERIMENT
-            const PathState s_saved = s;
-            if (rp.profile & 0x1000u) {            // machinery only: every path lives 4 (or 3) trips, no integrator work
-                if (had_path) {
-                    uint32_t depth = (s.flags & PF_DEPTH_MASK) + 1u;
-                    uint32_t h = (s.lane * 2654435761u + depth * 40503u) >> 28;
-                    s.flags = (s.flags & ~(PF_DEPTH_MASK | PF_MEDIUM_MASK | PF_NOHIT)) | depth | (h < 6 ? (1u << PF_MEDIUM_SHIFT) | PF_NOHIT : (h < 12 ? (1u << PF_MEDIUM_SHIFT) : 0u));
-                    alive = depth < ((rp.profile & 0x2000u) ? 3u : 4u); n_trips += 1;
-                }
-            } else
-#endif
             if (had_path) {
                 SamplerT<LD> rng = lane_rng_resume<LD>(rp, s.lane, s.rng_state);
                 if (INTEGRATOR == LRT_INTEGRATOR_PATH) alive = LDS_BVH ? path_iteration(sc, rp, s, rng, tr_lds, n_shadow) : path_iteration(sc, rp, s, rng, tr_glb, n_shadow);
@@ -787,25 +786,10 @@ k_render(ScenePtr scp, LaunchPtr lp) {
                 else if (INTEGRATOR == LRT_INTEGRATOR_VOLPATHMIS) alive = LDS_BVH ? volpathmis_iteration<true>(sc, rp, s, rng, tr_lds, n_shadow) : volpathmis_iteration<true>(sc, rp, s, rng, tr_glb, n_shadow);
                 else if (INTEGRATOR == LRT_INTEGRATOR_VOLPATHMIS_PLAIN) alive = LDS_BVH ? volpathmis_iteration<false>(sc, rp, s, rng, tr_lds, n_shadow) : volpathmis_iteration<false>(sc, rp, s, rng, tr_glb, n_shadow);
                 else if (INTEGRATOR == LRT_INTEGRATOR_VOLPATH_HET) alive = LDS_BVH ? volpath_iteration<true>(sc, rp, s, rng, tr_lds, n_shadow, n_extra) : volpath_iteration<true>(sc, rp, s, rng, tr_glb, n_shadow, n_extra);
-                else alive = LDS_BVH ? volpath_iteration<false>(sc, rp, s, rng, tr_lds, n_shadow, n_extra) : volpath_iteration<false>(sc, rp, s, rng, tr_glb, n_shadow, n_extra);
+                else { const bool fresh_tile = t >= ta + tc + tb; alive = LDS_BVH ? volpath_iteration<false>(sc, rp, s, rng, tr_lds, n_shadow, n_extra, fresh_tile) : volpath_iteration<false>(sc, rp, s, rng, tr_glb, n_shadow, n_extra, fresh_tile); }
                 s.rng_state = rng.state;
                 n_trips += 1;
             }
-#ifdef LRT_EXPERIMENT
-            // cost attribution: run the trip of the selected tile kinds a second time on a copy (result discarded)
-            {
-                const int kind = t < ta ? 0 : (t < ta + tc ? 1 : (t < ta + tc + tb ? 2 : 3));
-                if ((rp.profile >> (8 + kind)) & 1u) {
-                    PathState s2 = s_saved; bool alive2 = false; uint32_t d0 = 0, d1 = 0;
-                    if (had_path) {
-                        SamplerT<LD> rng = lane_rng_resume<LD>(rp, s2.lane, s2.rng_state);
-                        if (INTEGRATOR == LRT_INTEGRATOR_PATH) alive2 = LDS_BVH ? path_iteration(sc, rp, s2, rng, tr_lds, d0) : path_iteration(sc, rp, s2, rng, tr_glb, d0);
-                        else alive2 = LDS_BVH ? volpath_iteration<false>(sc, rp, s2, rng, tr_lds, d0, d1) : volpath_iteration<false>(sc, rp, s2, rng, tr_glb, d0, d1);
-                    }
-                    if (alive2 && s2.flags == 0xdeadbeefu) s.res.x += s2.res.x;
-                }
-            }
-#endif
             retire_and_compact_wave<MODE>(sc, rp, had_path, alive, s, A.film, A.sample_out, A.sample_base, parity ? A.q0 : A.q1, pool, P, s_out);
             if ((rp.profile & 1u) && lane_in_wave == 0) {
                 const int region = t < ta ? 0 : (t < ta + tc ? 1 : (t < ta + tc + tb ? 2 : 3));
