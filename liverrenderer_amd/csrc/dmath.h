@@ -309,6 +309,10 @@ template <bool LD>
 struct SamplerT {
     uint64_t state, inc;
     uint32_t ld_count;         // LD: the sampler's (rounded) sample count, wave-uniform
+    uint32_t ld_s1, ld_s2x, ld_s2y;   // LD: the 1-D and 2-D scrambles, functions of the per-pixel seed alone (ldsampler.cpp:118-121,133-137): evaluated once per trip (ld_prepare)
+    DEV void ld_prepare() {
+        if (LD) { uint32_t t; tea32((uint32_t) inc, 0x48bc48ebu, &ld_s1, &t); tea32((uint32_t) inc, 0x98bc51abu, &ld_s2x, &ld_s2y); }
+    }
     DEV uint32_t next_u32() {
         uint64_t old = state;
         state = old * 0x5851f42d4c957f2dULL + inc;
@@ -337,16 +341,14 @@ struct SamplerT {
     DEV float next() {
         if (LD) {
             const uint32_t i = ld_point();
-            uint32_t s0, s1; tea32((uint32_t) inc, 0x48bc48ebu, &s0, &s1);
-            return radical_inverse_2(i, s0);
+            return radical_inverse_2(i, ld_s1);
         }
         return u2f((next_u32() >> 9) | 0x3f800000u) - 1.f;
     }
     DEV void next2(float &x, float &y) {
         if (LD) {
             const uint32_t i = ld_point();
-            uint32_t sx, sy; tea32((uint32_t) inc, 0x98bc51abu, &sx, &sy);
-            x = radical_inverse_2(i, sx); y = sobol_2(i, sy);
+            x = radical_inverse_2(i, ld_s2x); y = sobol_2(i, ld_s2y);
             return;
         }
         x = u2f((next_u32() >> 9) | 0x3f800000u) - 1.f; y = u2f((next_u32() >> 9) | 0x3f800000u) - 1.f;

@@ -87,13 +87,13 @@ DEV uint64_t lane_rng_inc(RpRef rp, uint32_t lane) {
 template <bool LD>
 DEV SamplerT<LD> lane_rng_fresh(RpRef rp, uint32_t lane) {
     SamplerT<LD> r; r.ld_count = rp.ld_count;
-    if (LD) { r.state = 0; r.inc = lane_rng_inc<LD>(rp, lane); return r; }
+    if (LD) { r.state = 0; r.inc = lane_rng_inc<LD>(rp, lane); r.ld_prepare(); return r; }
     uint32_t v0, v1; tea32(rp.seed_value, lane, &v0, &v1);
     r.seed(v0, v1); return r;
 }
 template <bool LD>
 DEV SamplerT<LD> lane_rng_resume(RpRef rp, uint32_t lane, uint64_t state) {
-    SamplerT<LD> r; r.ld_count = rp.ld_count; r.state = state; r.inc = lane_rng_inc<LD>(rp, lane); return r;
+    SamplerT<LD> r; r.ld_count = rp.ld_count; r.state = state; r.inc = lane_rng_inc<LD>(rp, lane); r.ld_prepare(); return r;
 }
 // Rank-local index of a lane within the current pass (the index space of per-lane buffers)
 DEV uint64_t lane_local_index(RpRef rp, uint32_t lane) {
