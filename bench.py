@@ -15,6 +15,8 @@ film all-reduce when N > 1).  Default workload (`--config c3`): BASELINE config 
   --config multimesh    scenes/Liver-MultiMesh/mitsuba3/scene_temp.xml with its own defaults (`biovolpath`, both meshes, both tissue
                         media, envmap, 256 spp): the scene of BASELINE.md's published 44.6 s / 11.89 Msamples/s; `vs_baseline` is set
   --config c4           scenes/Liver-MultiMesh/mitsuba3/scene.xml as committed (BASELINE config C4's geometry), 1024 spp
+  --config het          SURVEY.md 8f row 4: `volpath` through a grid-volume medium (delta tracking, null collisions) in a box, 1080x1080, 64 spp
+  --config mis          the same scene plus a homogeneous medium under `volpathmis` (spectral MIS), 1080x1080, 64 spp
 
 For N > 1 the SAME image is sharded by 32x32 pixel tiles over the ranks (strong scaling) and the per-rank raw films are
 summed with one all-reduce before develop.  Prints ONE JSON line on rank 0 (contract: see the task statement).
@@ -35,8 +37,8 @@ HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8
 SCENES = os.path.join(ROOT, "scenes")
 
 # bytes of one path record across the SoA streams (csrc/device_types.h); PRB carries one more float4 stream (delta_L)
-RECORD_BYTES = {"path": 88, "volpath": 88, "biovolpath": 96, "biovolpath06": 96, "prbvolpath": 104}
-KERNEL_ID = {"path": 0, "volpath": 1, "biovolpath": 3, "biovolpath06": 4}
+RECORD_BYTES = {"path": 88, "volpath": 88, "biovolpath": 96, "biovolpath06": 96, "prbvolpath": 104, "volpathmis": 168, "volpath_het": 104}
+KERNEL_ID = {"path": 0, "volpath": 1, "biovolpath": 3, "biovolpath06": 4, "volpathmis": 5, "volpathmis_plain": 102, "volpath_het": 101}
 CONFIGS = {
     "c3": dict(scene=os.path.join(SCENES, "Liver-SingleMesh", "mitsuba3", "scene.xml"), integrator="volpath", spp=512, width=1920, height=1080,
                label="C3 Liver-SingleMesh {integrator} {w}x{h} {spp} spp max_depth 12 (homogeneous medium, isotropic phase, envmap)"),
@@ -59,6 +61,11 @@ CONFIGS = {
                       label="Liver-MultiMesh scene_temp.xml {integrator} (file defaults: capsule shell + parenchyma mesh, glissonCapsule + parenchyma media, envmap, ld sampler, tent) {w}x{h} {spp} spp max_depth 12"),
     "parenchyma": dict(scene=os.path.join(SCENES, "Parenchyma", "mitsuba3", "scene_temp.xml"), integrator=None, spp=256, width=1920, height=1080,
                        label="Parenchyma {integrator} (file defaults: parenchyma medium, ld sampler, tent) {w}x{h} {spp} spp max_depth 12"),
+    # SURVEY.md 8f row 4 (parity unpinned by the reference beyond analytic answers): the scenes of tests/test_round2_gpu.py at bench size
+    "het": dict(scene="generated:het", integrator=None, spp=64, width=1080, height=1080,
+                label="f4 heterogeneous (grid-volume) medium in a null-boundary box, {integrator} with delta tracking, area light + constant environment {w}x{h} {spp} spp max_depth 12"),
+    "mis": dict(scene="generated:mis", integrator=None, spp=64, width=1080, height=1080,
+                label="f4 {integrator} (spectral MIS) through a grid-volume medium and a homogeneous medium {w}x{h} {spp} spp max_depth 12"),
 }
 
 
@@ -79,6 +86,18 @@ def parse():
     return p.parse_args()
 
 
+def kernel_source_id():
+    """sha1 over the kernel sources the loaded library was built from (csrc/*.h, *.hip, *.cpp + include/liverrt.h).  profiles/*traffic.json
+    records it; `roofline.traffic` is taken from a traffic file only when the ids agree, else it is null."""
+    import hashlib
+    h = hashlib.sha1()
+    src = os.path.join(ROOT, "liverrenderer_amd", "csrc")
+    for f in sorted(os.listdir(src)):
+        if f.endswith((".h", ".hip", ".cpp")): h.update(f.encode()); h.update(open(os.path.join(src, f), "rb").read())
+    h.update(open(os.path.join(ROOT, "include", "liverrt.h"), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def usable_cores():
     """Host cores this process may actually use: the affinity mask, capped by the cgroup CPU quota (the GPU boxes expose
     all cores of the host but grant a share of them)."""
@@ -97,7 +116,19 @@ def usable_cores():
     return max(1, n)
 
 
+_TMP = []
+
+
 def load(mi, cfg, spp, w, h, integrator):
+    if cfg["scene"].startswith("generated:"):
+        import tempfile
+        import scene_gen
+        tmp = tempfile.mkdtemp(prefix="lrt_bench_"); _TMP.append(tmp)
+        vol = os.path.join(tmp, "smoke.vol"); mi.write_volume_grid(vol, scene_gen.smoke_grid())
+        xml = scene_gen.het_xml(vol) if cfg["scene"] == "generated:het" else scene_gen.two_media_xml(vol).replace(
+            '<integrator type="volpath">', '<integrator type="volpathmis"><boolean name="use_spectral_mis" value="true"/>')
+        if integrator: xml = xml.replace('<integrator type="volpath">', f'<integrator type="{integrator}">')
+        return mi.load_string(scene_gen.resized(xml, w, h, spp))
     if cfg["scene"] == "cornell_box":
         d = mi.cornell_box()
         d["sensor"]["film"]["width"], d["sensor"]["film"]["height"] = w, h
@@ -195,7 +226,11 @@ def main():
     # radiance for the splat pass / the adjoint replay, which reads it back).  Duration: HIP events around the launches on the
     # library's stream (kernel_ms).  BASELINE.md "Roofline accounting" states the same model.
     n_rank = st["n_samples"]
-    rec_b = RECORD_BYTES[integrator]
+    has_het = any(scene.desc.media[i].type == _lib.MEDIUM["heterogeneous"] for i in range(scene.desc.n_media))
+    kkey = integrator
+    if integrator == "volpath" and has_het: kkey = "volpath_het"                       # 104-B records: the kept surface hit rides along
+    if integrator == "volpathmis" and not scene.desc.use_spectral_mis: kkey = "volpathmis_plain"
+    rec_b = RECORD_BYTES["volpathmis" if integrator == "volpathmis" else kkey]
     box = scene.desc.film.rfilter == 0
     if backward: out_bytes = 2.0 * 16.0 * n_rank * a.steps
     elif box: out_bytes = 4.0 * C * w * h * a.steps / max(world, 1)
@@ -204,25 +239,28 @@ def main():
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
     workload = cfg["label"].format(integrator=integrator, w=w, h=h, spp=spp)
     # HBM traffic per launch from the PMC passes of the same workload (scripts/profile_bench.sh -> profiles/*traffic.json)
-    traffic = None
+    # (a counter pass cannot run inside this process: rocprofv3 wraps the program; the file must come from THIS build of the kernels)
+    traffic = None; traffic_file = None; ksid = kernel_source_id()
     for tf in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic*.json"))):
         try:
             tj = json.load(open(tf))
-            if tj.get("workload") == workload and world == 1: traffic = tj["traffic_bytes_per_launch"]
+            if tj.get("workload") == workload and world == 1 and tj.get("kernel_source_id") == ksid:
+                traffic = tj["traffic_bytes_per_launch"]; traffic_file = os.path.basename(tf)
         except Exception:
             pass
     ld = scene.desc.sampler_type == 1
     lds = bool(st.get("lds_resident", 1))                      # False: the mesh did not fit the LDS image, BVH in global memory, 256-thread workgroups
     geom = "1024, true" if lds else "256, false"
-    kname = ("lrt::k_render_prb<*, %s, %s>" % (geom, str(ld).lower())) if backward else ("lrt::k_render<%d, %s, %s>" % (KERNEL_ID[integrator], geom, str(ld).lower()))
+    kname = ("lrt::k_render_prb<*, %s, %s>" % (geom, str(ld).lower())) if backward else ("lrt::k_render<%d, %s, %s>" % (KERNEL_ID[kkey], geom, str(ld).lower()))
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "kernel": kname,
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_file, "kernel_source_id": ksid, "kernel": kname,
                 "launches_per_step": launches / a.steps, "avg_launch_ms": kern_ms / max(launches, 1),
                 "alg_bytes_per_launch": alg_bytes / max(launches, 1), "record_bytes": rec_b,
                 "iterations_per_sample": iters / (n_rank * a.steps), "records_per_sample": records / (n_rank * a.steps),
                 "shadow_queries_per_sample": shadows / (n_rank * a.steps)}
 
-    data = "mi.cornell_box() dictionary" if cfg["scene"] == "cornell_box" else "reference scene files (scene xml, liver2.obj, tissue_n.png, cavidade_latitude.exr)"
+    data = ("mi.cornell_box() dictionary" if cfg["scene"] == "cornell_box" else "synthetic: generated scene (tests/scene_gen.py), random density grid" if cfg["scene"].startswith("generated:")
+            else "reference scene files (scene xml, liver2.obj, tissue_n.png, cavidade_latitude.exr)")
     out = {"metric": "Msamples/s", "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": a.steps,
            "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
            "vs_baseline": None, "dtype": "f32", "data": data,
@@ -237,7 +275,8 @@ def main():
         out["config"]["published"] = {"value": cfg["published_msamples"], "unit": "Msamples/s", "source": "scenes/Liver-MultiMesh/mitsuba3/time.txt (BASELINE.md), GPU unstated"}
 
     if rank == 0 and world == 1 and not backward:
-        # SURVEY.md 8d's form of the metric: lrt_render entry to the developed image AND raw film in host memory (PCIe included)
+        # SURVEY.md 8d's form of the metric: lrt_render entry to the developed image AND raw film in host memory (PCIe included).
+        # Reported beside `value`, never as it: the bench contract takes `value` with everything resident in HBM.
         scene.render(spp=spp, seed=77, return_raw=True)
         t1 = time.perf_counter()
         for i in range(max(1, a.steps)): scene.render(spp=spp, seed=i, return_raw=True)
@@ -245,34 +284,74 @@ def main():
         out["host_visible"] = {"value": round(n_samples / hdt / 1e6, 3), "unit": "Msamples/s", "ms_per_step": round(hdt * 1e3, 3),
                                "note": "lrt_render with host output buffers: developed image + raw film copied over PCIe inside the call (SURVEY.md 8d t_render); reported beside `value`, never as it"}
 
+    if rank == 0 and world == 1 and a.config == "c3" and not (a.scene or a.integrator):
+        # BASELINE.json config 3 is worded "homogeneous medium + HG phase"; the scene file says isotropic.  The driver's
+        # default line carries both: `value` on the file as committed, `hg_phase` on the same workload with the phase function set to
+        # HG, g = 0.7, through the parameter interface (mi.traverse) - same size, same timed region, same number of steps.
+        hg = load(mi, CONFIGS["c3hg"], spp, w, h, integrator_override)
+        dev = torch.device("cuda", local_rank)
+        film = torch.zeros((h, w, C), dtype=torch.float32, device=dev); image = torch.empty((h, w, C - 1), dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()
+        hg.render_to_device(film.data_ptr(), image.data_ptr(), spp=spp, seed=999, device=local_rank)
+        torch.cuda.synchronize(); t1 = time.perf_counter(); hk = hi = hr = 0.0
+        for i in range(a.steps):
+            hg.render_to_device(film.data_ptr(), image.data_ptr(), spp=spp, seed=i, device=local_rank)
+            hs = hg.stats(); hk += hs["kernel_ms"]; hi += hs["n_iter"]; hr += hs["n_records"]
+        torch.cuda.synchronize(); hdt = (time.perf_counter() - t1) / a.steps
+        hb = 2.0 * RECORD_BYTES["volpath"] * hr + 4.0 * C * w * h * a.steps
+        out["hg_phase"] = {"value": round(n_samples / hdt / 1e6, 3), "unit": "Msamples/s", "ms_per_step": round(hdt * 1e3, 3), "g": 0.7,
+                           "workload": CONFIGS["c3hg"]["label"].format(integrator=integrator, w=w, h=h, spp=spp),
+                           "roofline_frac": round(hb / (hk * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if hk > 0 else None,
+                           "iterations_per_sample": hi / (n_samples * a.steps), "records_per_sample": hr / (n_samples * a.steps)}
+
     if rank == 0 and world == 1 and not a.no_cpu_baseline and not backward:
-        # ---- CPU baseline: the oracle (our restatement of the reference's CPU path) on the host cores,
-        # same scene/resolution at a reduced spp, and the GPU-vs-oracle RMSE at that spp (same seed).
+        # ---- CPU baseline (reported, not a target): the oracle's scalar_rgb restatement - SamplingIntegrator::render's scalar branch,
+        # 32x32 blocks in Morton order, one std::thread per granted core (oracle/orc_render.cpp orc_render_scalar; SURVEY.md 8d,
+        # BASELINE.md section 3.5) - on a bounded sample of the same workload: same scene and resolution at a reduced spp.
+        # Built here with -O3 -march=native for the box's own host CPU when g++ is present (the shipped liborc.so is -O2 -mfma so that
+        # it runs on any x86-64-v3 host); both builds keep -ffp-contract=off and give the same numbers (tests/test_oracle_pins.py).
+        import subprocess, tempfile
         import orc
         cores = usable_cores()
+        flags = "g++ -O2 -mfma -ffp-contract=off (shipped oracle/liborc.so)"
+        try:
+            tmp = tempfile.mkdtemp(prefix="lrt_orc_"); _TMP.append(tmp)
+            native = os.path.join(tmp, "liborc_native.so")
+            src = [os.path.join(ROOT, "oracle", f) for f in ("orc_scene.cpp", "orc_render.cpp", "orc_api.cpp", "orc_vae.cpp")]
+            subprocess.run(["g++", "-O3", "-march=native", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-pthread", "-shared", "-o", native] + src,
+                           check=True, capture_output=True, timeout=300)
+            orc.use_library(native); flags = "g++ -O3 -march=native -ffp-contract=off -fno-fast-math, built on this host"
+        except Exception:
+            pass
         if a.cpu_spp <= 0:                       # calibrate on 1 spp so that the sample takes ~15 s of wall time
             cs = load(mi, cfg, 1, w, h, integrator_override)
             c_spp1 = cs.spp
-            t1 = time.perf_counter(); orc.OrcScene(cs).render(threads=cores, seed=0); c1 = (time.perf_counter() - t1) / c_spp1
+            t1 = time.perf_counter(); orc.OrcScene(cs).render(threads=cores, seed=0, scalar=True); c1 = (time.perf_counter() - t1) / c_spp1
             a.cpu_spp = int(min(spp, max(1, round(15.0 / max(c1, 1e-3)))))
         cs = load(mi, cfg, a.cpu_spp, w, h, integrator_override)
         cpu_spp = cs.spp
         o = orc.OrcScene(cs)
         t1 = time.perf_counter()
-        cimg = o.render(threads=cores, seed=0)
+        o.render(threads=cores, seed=0, scalar=True)
         ct = time.perf_counter() - t1
-        gimg = cs.render(seed=0)
-        rmse = float(np.sqrt(np.mean((gimg.astype(np.float64) - cimg.astype(np.float64)) ** 2)))
         out["cpu_baseline"] = {"value": round(w * h * cpu_spp / ct / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
                                "sample": f"same scene and resolution at {cpu_spp} spp ({w * h * cpu_spp} samples, {ct:.1f} s)",
-                               "build": "oracle/liborc.so: g++ -O2 -mfma -ffp-contract=off, scalar C++ restatement with llvm_ad_rgb lane semantics, one std::thread per granted core"}
-        out["rmse_vs_oracle"] = {"value": rmse, "spp": cpu_spp, "tolerance": 1e-4,
-                                 "note": "same seed: per-lane radiance is bit-identical, the film differs by float-atomic order only"}
+                               "build": f"oracle (scalar C++ restatement of the reference's scalar_rgb render loop, orc_render_scalar): {flags}; one std::thread per granted core"}
+        # ---- RMSE against the llvm_ad_rgb restatement (lane semantics, same seeding as the GPU): same seed, a sample of <= 4 spp
+        r_spp = max(1, min(cpu_spp, 4))
+        rs = load(mi, cfg, r_spp, w, h, integrator_override); r_spp = rs.spp
+        cimg = orc.OrcScene(rs).render(threads=cores, seed=0)
+        gimg = rs.render(seed=0)
+        rmse = float(np.sqrt(np.mean((gimg.astype(np.float64) - cimg.astype(np.float64)) ** 2)))
+        out["rmse_vs_oracle"] = {"value": rmse, "spp": r_spp, "tolerance": 1e-4,
+                                 "note": "against the oracle's llvm_ad_rgb lane semantics at the same seed: per-lane radiance is bit-identical, the film differs by float-atomic order only"}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    import shutil
+    for t in _TMP: shutil.rmtree(t, ignore_errors=True)
 
 
 if __name__ == "__main__":

@@ -277,9 +277,12 @@ class Scene:
         return out
 
     def render_backward(self, grad_image, **kw):
+        """PRB adjoint.  `medium`: index of the medium whose sigma_t / albedo / g the gradients refer to; the default -1 sums the adjoint
+        over all media into one parameter set (the round-1 meaning; lrt_render_opts.grad_medium in the C ABI, where a zero-initialised
+        struct selects medium 0)."""
         g = np.ascontiguousarray(grad_image, dtype=np.float32)
         o = make_opts(kw.get("integrator"), kw.get("max_depth"), kw.get("rr_depth"), kw.get("hide_emitters"), kw.get("spp", 0),
-                      kw.get("seed", 0), kw.get("tile_rank", 0), kw.get("tile_count", 1), kw.get("device", 0), grad_medium=kw.get("medium", 0))
+                      kw.get("seed", 0), kw.get("tile_rank", 0), kw.get("tile_count", 1), kw.get("device", 0), grad_medium=kw.get("medium", -1))
         out = _lib.ParamGrads()
         _lib.check(self._lib.lrt_render_backward(self._h, C.byref(o), g.ctypes.data, C.byref(out)))
         return {"sigma_t": np.array(out.d_sigma_t[:], dtype=np.float32), "albedo": np.array(out.d_albedo[:], dtype=np.float32),

@@ -116,11 +116,35 @@ def make_opts(integrator=None, max_depth=None, rr_depth=None, hide_emitters=None
 _lib = None
 
 
+def _pytorch_context_first():
+    """The PyTorch-ROCm wheel carries its own libamdhip64.so while libliverrt.so links the system one: a process that uses both must
+    let PyTorch create its HIP context BEFORE libliverrt's first device call, or PyTorch is left without a device ("No HIP GPUs are
+    available") - on an 8-rank launch one mis-ordered import is a whole-job failure.  So when PyTorch is importable its context is
+    created here, before the library is loaded, whatever order the caller imports things in.  LRT_NO_TORCH_INIT=1 skips this (a process
+    that never uses PyTorch saves the import).  Returns what was done, for the tests."""
+    import importlib.util
+    import sys
+    if os.environ.get("LRT_NO_TORCH_INIT"):
+        return "skipped"
+    if "torch" not in sys.modules and importlib.util.find_spec("torch") is None:
+        return "no torch"
+    import torch
+    if not torch.cuda.is_available():
+        return "no device"
+    if not torch.cuda.is_initialized():
+        torch.zeros(1, device="cuda")
+    if not torch.cuda.is_initialized():
+        raise RuntimeError("PyTorch is importable but its HIP context could not be created before libliverrt.so was loaded; "
+                           "set LRT_NO_TORCH_INIT=1 if this process does not use PyTorch")
+    return "initialised"
+
+
 def lib():
     """Load libliverrt.so and declare the signatures of every exported symbol."""
     global _lib
     if _lib is not None:
         return _lib
+    _pytorch_context_first()
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(the hip_ad_rgb back-end has no CPU fallback)")

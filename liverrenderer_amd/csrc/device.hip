@@ -51,6 +51,7 @@ struct DeviceScene {
     const unsigned long long *cur_pass_in = nullptr; unsigned long long *cur_pass_out = nullptr;
     uint32_t *pixel_slot = nullptr;         // inverse of pixel_list (pixel -> index in the list), tile-sharded renders
     uint32_t *pixel_list = nullptr; uint32_t pixel_list_rank = 0xffffffffu, pixel_list_count = 0, n_owned_pixels = 0;
+    uint32_t *halo_list = nullptr; uint32_t halo_rank = 0xffffffffu, halo_count = 0, halo_width = 0, n_halo_pixels = 0;   // own tiles dilated by `halo_width` pixels (PRB weight film)
     std::vector<hipEvent_t> ev_pool;
     std::vector<DMedium> h_media; DMedium *d_media = nullptr;
     std::vector<DBioMedium> h_bio; DBioMedium *d_bio = nullptr;
@@ -483,22 +484,26 @@ void device_scene_update_params(DeviceScene *D, const lrt_scene_desc &d) {
 
 static void ensure_workspace(DeviceScene *D, uint32_t capacity) {
     if (D->capacity >= capacity && D->mis_alloc == D->need_mis) return;
-    D->mis_alloc = D->need_mis;
-    auto alloc_q = [&](DPathStreams &q) {
-        D->release(q.o_maxt); D->release(q.d_eta); D->release(q.tp_pdf); D->release(q.res_flags); D->release(q.lp_lane); D->release(q.rng); D->release(q.tdepth); D->release(q.hit); q.hit = nullptr; D->release(q.w1); D->release(q.w2); D->release(q.w3); D->release(q.w4); q.w1 = q.w2 = q.w3 = q.w4 = nullptr;
-        HIP_CHECK(hipMalloc((void **) &q.o_maxt, (size_t) capacity * 16)); D->track(q.o_maxt);
-        HIP_CHECK(hipMalloc((void **) &q.d_eta, (size_t) capacity * 16)); D->track(q.d_eta);
-        HIP_CHECK(hipMalloc((void **) &q.tp_pdf, (size_t) capacity * 16)); D->track(q.tp_pdf);
-        HIP_CHECK(hipMalloc((void **) &q.res_flags, (size_t) capacity * 16)); D->track(q.res_flags);
-        HIP_CHECK(hipMalloc((void **) &q.lp_lane, (size_t) capacity * 16)); D->track(q.lp_lane);
-        HIP_CHECK(hipMalloc((void **) &q.rng, (size_t) capacity * 8)); D->track(q.rng);
-        HIP_CHECK(hipMalloc((void **) &q.tdepth, (size_t) capacity * 8)); D->track(q.tdepth);
-        if (D->has_het || D->need_mis) { HIP_CHECK(hipMalloc((void **) &q.hit, (size_t) capacity * 16)); D->track(q.hit); }
-        if (D->need_mis) for (float4 **w : { &q.w1, &q.w2, &q.w3, &q.w4 }) { HIP_CHECK(hipMalloc((void **) w, (size_t) capacity * 16)); D->track(*w); }
-    };
     HIP_CHECK(hipStreamSynchronize(D->stream));
-    alloc_q(D->q[0]); alloc_q(D->q[1]);
-    D->capacity = capacity;
+    // Exception safety: the old streams are released and every pointer cleared BEFORE anything is allocated, and capacity / mis_alloc are
+    // set only after every allocation succeeded: a failed hipMalloc (out of memory) leaves capacity = 0, so the next render allocates again
+    // instead of launching on freed memory.
+    const bool want_mis = D->need_mis;
+    D->capacity = 0;
+    for (DPathStreams *q : { &D->q[0], &D->q[1] }) {
+        for (void *p : { (void *) q->o_maxt, (void *) q->d_eta, (void *) q->tp_pdf, (void *) q->res_flags, (void *) q->lp_lane, (void *) q->rng, (void *) q->tdepth,
+                         (void *) q->hit, (void *) q->w1, (void *) q->w2, (void *) q->w3, (void *) q->w4 }) D->release(p);
+        *q = DPathStreams{};
+    }
+    auto alloc = [&](size_t bytes) { void *p = nullptr; HIP_CHECK(hipMalloc(&p, bytes)); D->track(p); return p; };
+    for (DPathStreams *q : { &D->q[0], &D->q[1] }) {
+        q->o_maxt = (float4 *) alloc((size_t) capacity * 16); q->d_eta = (float4 *) alloc((size_t) capacity * 16); q->tp_pdf = (float4 *) alloc((size_t) capacity * 16);
+        q->res_flags = (float4 *) alloc((size_t) capacity * 16); q->lp_lane = (float4 *) alloc((size_t) capacity * 16);
+        q->rng = (uint2 *) alloc((size_t) capacity * 8); q->tdepth = (float2 *) alloc((size_t) capacity * 8);
+        if (D->has_het || want_mis) q->hit = (float4 *) alloc((size_t) capacity * 16);
+        if (want_mis) for (float4 **w : { &q->w1, &q->w2, &q->w3, &q->w4 }) *w = (float4 *) alloc((size_t) capacity * 16);
+    }
+    D->capacity = capacity; D->mis_alloc = want_mis;
 }
 
 static hipEvent_t get_event(DeviceScene *D, size_t i) {
@@ -510,6 +515,7 @@ static hipEvent_t get_event(DeviceScene *D, size_t i) {
 struct ResolvedOpts { int integrator, max_depth, rr_depth, hide_emitters; uint32_t spp, seed, tile_rank, tile_count; uint32_t spp_total = 0, n_passes = 1, pass = 0; };
 static ResolvedOpts resolve(const lrt_scene_desc &d, const lrt_render_opts *o) {
     ResolvedOpts r;
+    if (o && o->integrator > LRT_INTEGRATOR_VOLPATHMIS) throw std::invalid_argument("lrt_render_opts.integrator " + std::to_string(o->integrator) + " is not an integrator (LRT_INTEGRATOR_PATH .. LRT_INTEGRATOR_VOLPATHMIS, or -1 for the scene's own)");
     r.integrator = (o && o->integrator >= 0) ? o->integrator : d.integrator.type;
     r.max_depth = (o && o->max_depth != -2) ? o->max_depth : d.integrator.max_depth;
     r.rr_depth = (o && o->rr_depth >= 0) ? o->rr_depth : d.integrator.rr_depth;
@@ -555,6 +561,28 @@ static void ensure_pixel_list(DeviceScene *D, const ResolvedOpts &O) {
     for (size_t k = 0; k < px.size(); ++k) inv[px[k]] = (uint32_t) k;
     D->pixel_slot = D->track(dev_upload(inv.data(), inv.size(), D->stream));
     D->pixel_list_rank = O.tile_rank; D->pixel_list_count = O.tile_count; D->n_owned_pixels = (uint32_t) px.size();
+}
+
+// The rank's tiles dilated by `halo` pixels, as a pixel list (row-major order inside the dilated tiles, every pixel once).  The PRB
+// adjoint normalises by the per-pixel sum of reconstruction-filter weights (common.py:730-746): a rank reads that sum at the pixels its
+// own lanes' footprints touch (own tiles + fn pixels), and those sums are complete once every lane within fn of them has been added:
+// halo = 2 fn.  Without this every rank would walk all W H spp lanes of the image.
+static void ensure_halo_list(DeviceScene *D, const ResolvedOpts &O, uint32_t halo) {
+    const DFilm &F = D->sc.film;
+    if (D->halo_list && D->halo_rank == O.tile_rank && D->halo_count == O.tile_count && D->halo_width == halo) return;
+    std::vector<uint8_t> mark((size_t) F.width * F.height, 0);
+    const uint32_t tx = (F.width + 31) / 32, ty = (F.height + 31) / 32;
+    for (uint32_t t = O.tile_rank; t < tx * ty; t += O.tile_count) {
+        const int x0 = (int) (t % tx) * 32 - (int) halo, y0 = (int) (t / tx) * 32 - (int) halo;
+        const int x1 = std::min<int>((int) (t % tx) * 32 + 32, F.width) + (int) halo, y1 = std::min<int>((int) (t / tx) * 32 + 32, F.height) + (int) halo;
+        for (int y = std::max(y0, 0); y < std::min(y1, (int) F.height); ++y)
+            for (int x = std::max(x0, 0); x < std::min(x1, (int) F.width); ++x) mark[(size_t) y * F.width + x] = 1;
+    }
+    std::vector<uint32_t> px;
+    for (size_t k = 0; k < mark.size(); ++k) if (mark[k]) px.push_back((uint32_t) k);
+    D->release(D->halo_list); D->halo_list = nullptr;
+    D->halo_list = D->track(dev_upload(px.data(), px.size(), D->stream));
+    D->halo_rank = O.tile_rank; D->halo_count = O.tile_count; D->halo_width = halo; D->n_halo_pixels = (uint32_t) px.size();
 }
 
 static void ensure_prb_workspace(DeviceScene *D, uint32_t records, uint64_t l_buf_lanes) {
@@ -908,12 +936,14 @@ void device_render_backward(DeviceScene *D, const lrt_scene_desc &d, const lrt_r
     if (F.rfilter != LRT_RFILTER_BOX) {
         if (D->wfilm_floats < np) { D->release(D->wfilm); D->wfilm = nullptr; HIP_CHECK(hipMalloc((void **) &D->wfilm, np * 4)); D->track(D->wfilm); D->wfilm_floats = np; }
         HIP_CHECK(hipMemsetAsync(D->wfilm, 0, np * 4, st));
-        // sum of reconstruction-filter weights per pixel over every lane of the image (also those of other ranks' tiles)
-        uint64_t all = (uint64_t) np * O.spp;
+        // sum of reconstruction-filter weights per pixel: over every lane of the image, or (tile-sharded) over the lanes of the rank's
+        // tiles dilated by 2 fn pixels, which completes the sums at every pixel the rank's own footprints read (ensure_halo_list)
+        const uint32_t *wlist = nullptr; uint64_t all = (uint64_t) np * O.spp;
+        if (O.tile_count > 1) { ensure_halo_list(D, O, 2u * (uint32_t) F.fn); wlist = D->halo_list; all = (uint64_t) D->n_halo_pixels * O.spp; }
         DRenderParams rw = make_params(d, O, all);
         for (uint64_t base = 0; base < all; base += (1ull << 30)) {
             const uint64_t n = std::min<uint64_t>(1ull << 30, all - base);
-            DLaunch a{}; a.rp = rw; a.lane_begin = base; a.n = n; a.film = D->wfilm;
+            DLaunch a{}; a.rp = rw; a.lane_begin = base; a.n = n; a.film = D->wfilm; a.pixel_list = wlist;
             k_splat_lanes<true><<<(uint32_t) ((n + LRT_BLOCK - 1) / LRT_BLOCK), LRT_BLOCK, 0, st>>>((ScenePtr) D->d_sc, push_launch(D, a));
         }
     }

@@ -21,7 +21,9 @@ def tile_pixels(rank, world, width, height):
 
 
 def develop(raw):
-    """HDRFilm::develop (src/films/hdrfilm.cpp:306-410) on a torch / numpy raw film: RGB[A] / W, W == 0 -> 1."""
+    """HDRFilm::develop (src/films/hdrfilm.cpp:306-410) on a HOST raw film (numpy / CPU tensor): RGB[A] / W, W == 0 -> 1.  Used
+    only by the CPU rehearsal of render_distributed (a `render_rank_fn` on gloo, no GPU in the process); on a GPU the reduced film
+    is developed by the library's kernel (Scene.develop -> lrt_film_develop -> k_develop)."""
     w = raw[..., -1:]
     w = w + (w == 0)
     return raw[..., :-1] / w
@@ -50,6 +52,11 @@ def render_distributed(scene, render_rank_fn=None, spp=0, seed=0, group=None, **
         render_rank_fn(rank, world, film)
     if world > 1:
         dist.all_reduce(film, op=dist.ReduceOp.SUM, group=group)
+    if film.is_cuda:                                  # develop after the reduction, on the device, through the C ABI
+        image = torch.empty((h, w, C - 1), dtype=torch.float32, device=film.device)
+        torch.cuda.synchronize(film.device)           # the all-reduce ran on PyTorch's stream, the library has its own
+        scene.develop(film_ptr=film.data_ptr(), image_ptr=image.data_ptr())
+        return image, film
     return develop(film), film
 
 

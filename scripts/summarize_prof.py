@@ -29,7 +29,15 @@ for k in agg:
     print("== derived,", k)
     if "GRBM_GUI_ACTIVE" in a and "SQ_ACTIVE_INST_VALU" in a:
         cyc = a["GRBM_GUI_ACTIVE"] / 8.0                      # summed over the 8 XCDs
-        print(f"   GPU-active cycles {cyc:.4g}; VALU busy {a['SQ_ACTIVE_INST_VALU'] / (cyc * 1024 / 4):.1%} of SIMD quad-cycles (256 CUs x 4 SIMDs)")
+        # Two figures, neither a "fraction busy" in the strict sense (the old "VALU busy" printed 105 - 116 % on some
+        # configurations).  (i) issue-slot occupancy: a wave64 VALU instruction holds its SIMD's issue port for 4 cycles
+        # (MI355X_MICROARCH.md, "vector-instruction ISSUE cost"; transcendentals 8, so this is a LOWER bound of the port's busy time):
+        # SQ_INSTS_VALU x 4 / (cycles x 1024 SIMDs).  (ii) the sum over waves of quad-cycles with a VALU instruction in flight over the SIMD
+        # quad-cycles: in-flight intervals of different waves overlap in the pipeline, so this one can exceed 100 % and is only a
+        # relative measure between builds of the same kernel.
+        if "SQ_INSTS_VALU" in a:
+            print(f"   GPU-active cycles {cyc:.4g}; VALU issue-slot occupancy >= {a['SQ_INSTS_VALU'] * 4 / (cyc * 1024):.1%} (SQ_INSTS_VALU x 4 cycles / (cycles x 1024 SIMDs))")
+        print(f"   VALU in-flight quad-cycles, summed over waves / SIMD quad-cycles: {a['SQ_ACTIVE_INST_VALU'] / (cyc * 1024 / 4):.2f} (not a fraction: overlapping waves; relative measure only)")
     if "SQ_THREAD_CYCLES_VALU" in a and "SQ_ACTIVE_INST_VALU" in a:
         print(f"   VALU lane utilisation {a['SQ_THREAD_CYCLES_VALU'] / (a['SQ_ACTIVE_INST_VALU'] * 64):.1%}")
     if "SQ_WAIT_ANY" in a and "SQ_WAVE_CYCLES" in a:
@@ -43,7 +51,14 @@ for k in agg:
             workload = json.loads(line)["config"]["workload"]
         except Exception:
             pass
-        json.dump({"kernel": k, "workload": workload, "read_bytes_per_launch": rd, "write_bytes_per_launch": wr,
+        ksid = None
+        try:
+            sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+            import bench
+            ksid = bench.kernel_source_id()
+        except Exception:
+            pass
+        json.dump({"kernel": k, "workload": workload, "kernel_source_id": ksid, "read_bytes_per_launch": rd, "write_bytes_per_launch": wr,
                    "traffic_bytes_per_launch": rd + wr, "bench_args": sys.argv[2:],
                    "fetch_factor": FETCH_FACTOR,
                    "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), KiB; FETCH_SIZE x fetch_factor (guide value, reproduced on the record streams: profiles/r02_stream_calibration.txt)"},

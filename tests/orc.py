@@ -24,6 +24,12 @@ def build():
     subprocess.run(["make", "-s", "-C", ORC_DIR], check=True)
 
 
+def use_library(path):
+    """Load another build of the oracle from now on (bench.py's CPU baseline: a -O3 -march=native build made on the host it runs on)."""
+    global _orc, ORC_LIB
+    ORC_LIB = path; _orc = None
+
+
 def lib():
     global _orc
     if _orc is not None:
@@ -143,7 +149,7 @@ class OrcScene:
     def render_backward(self, grad_image, threads=0, **kw):
         g = np.ascontiguousarray(grad_image, np.float32)
         o = _lib.make_opts(kw.get("integrator"), kw.get("max_depth"), kw.get("rr_depth"), kw.get("hide_emitters"),
-                           kw.get("spp", 0), kw.get("seed", 0), grad_medium=kw.get("medium", 0))
+                           kw.get("spp", 0), kw.get("seed", 0), grad_medium=kw.get("medium", -1))
         out = _lib.ParamGrads()
         if self._L.orc_render_backward(self._h, C.byref(o), threads, g.ctypes.data, C.byref(out)) != 0:
             raise RuntimeError("orc_render_backward failed")

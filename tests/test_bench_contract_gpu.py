@@ -33,17 +33,36 @@ def test_bench_line_n1():
     ro = j["roofline"]
     assert ro["bound"] == "hbm" and ro["unit"] == "GB/s" and ro["peak"] == 8000.0 and abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-4
     assert ro["kernel"].startswith("lrt::k_render<1, 1024, true") and ro["avg_launch_ms"] > 0 and ro["avg_launch_ms"] <= j["ms_per_step"] * 1.001
+    assert ro["traffic"] is None or ro["traffic_source"]            # traffic only from a profile of THIS build of the kernels (kernel_source_id)
     cb = j["cpu_baseline"]
-    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "spp" in cb["sample"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "spp" in cb["sample"] and "orc_render_scalar" in cb["build"]
     assert j["rmse_vs_oracle"]["value"] <= j["rmse_vs_oracle"]["tolerance"]
+    hg = j["hg_phase"]                                            # BASELINE.json config 3 as worded (HG phase) rides in the default line
+    assert hg["g"] == 0.7 and hg["value"] > 0 and "HG phase" in hg["workload"]
+    assert j["host_visible"]["value"] > 0 and j["host_visible"]["value"] <= j["value"] * 1.05
 
 
-def test_bench_line_two_ranks_gloo():
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(29700 + os.getpid() % 200),
-           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--spp", "8", "--backend", "gloo"]
+@pytest.mark.parametrize("config,samples", [("c3", 1920 * 1080 * 8), ("c2", 1080 * 1080 * 8), ("c5", 1920 * 1080 * 16)])
+def test_bench_line_two_ranks_gloo(config, samples):
+    """the driver's N = 2 launch line (gloo instead of RCCL: both ranks share the box's one GPU): film all-reduce + develop for the
+    forward configurations, gradient all-reduce for the PRB one (c5: ld sampler, 8 -> 16 spp; tent filter: weight film over tiles + halo)"""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(29700 + (os.getpid() + len(config) * 7 + samples) % 200),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--spp", "8", "--backend", "gloo", "--config", config]
     r = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, env=ENV, timeout=600)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     j = last_json(r.stdout)
-    assert j["n_gpus"] == 2 and j["scaling"] == "strong" and "cpu_baseline" not in j
-    assert j["config"]["samples_per_step"] == 1920 * 1080 * 8 and j["value"] > 0
+    assert j["n_gpus"] == 2 and j["scaling"] == "strong" and "cpu_baseline" not in j and "hg_phase" not in j
+    assert j["config"]["samples_per_step"] == samples and j["value"] > 0
     assert "2 GPUs" in j["config"]["parallelism"]
+
+
+@pytest.mark.parametrize("config", ["het", "mis"])
+def test_bench_f4_configs(config):
+    """SURVEY.md 8f row 4 has bench configurations of its own: a short run of each prints a line whose roofline names
+    the heterogeneous-media / volpathmis kernel and prices its wider record."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", config, "--steps", "1", "--warmup", "1", "--spp", "4", "--width", "256", "--height", "256", "--no-cpu-baseline"],
+                       capture_output=True, text=True, cwd=ROOT, env=ENV, timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    j = last_json(r.stdout); ro = j["roofline"]
+    assert ro["kernel"].startswith("lrt::k_render<101," if config == "het" else "lrt::k_render<5,") and ro["record_bytes"] == (104 if config == "het" else 168)
+    assert j["value"] > 0 and ro["records_per_sample"] > 0 and j["data"].startswith("synthetic")

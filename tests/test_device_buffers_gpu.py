@@ -17,3 +17,11 @@ pytestmark = pytest.mark.gpu
 def test_device_buffers_match_host_buffers(case):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "device_buffers_worker.py"), case], capture_output=True, text=True, cwd=ROOT, timeout=600)
     assert r.returncode == 0 and f"ok {case}" in r.stdout, (r.stdout + r.stderr)[-3000:]
+
+
+@pytest.mark.parametrize("order", ["lrt_first", "torch_first"])
+def test_import_order_gpu(order):
+    """either import order of liverrenderer_amd and torch leaves both with the GPU (the binding creates PyTorch's
+    context before it loads libliverrt.so)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "import_order_worker.py"), order], capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert r.returncode == 0 and f"ok {order}" in r.stdout, (r.stdout + r.stderr)[-3000:]

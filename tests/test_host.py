@@ -397,3 +397,14 @@ def test_bench_configs_load_on_the_host(mi):
         for k, v in (cfg.get("params") or {}).items():
             assert np.allclose(mi.traverse(sc)[k], v), (key, k)
     assert bench.CONFIGS["c3hg"]["params"]["LiverMedium.phase_function.g"] == 0.7
+
+
+def test_pytorch_context_guard_without_a_gpu(monkeypatch):
+    """_lib._pytorch_context_first(): with PyTorch importable it is imported before libliverrt.so is loaded (here: no device, nothing to
+    initialise); LRT_NO_TORCH_INIT=1 opts out."""
+    from liverrenderer_amd import _lib
+    import torch
+    expected = "initialised" if torch.cuda.is_available() else "no device"
+    assert _lib._pytorch_context_first() == expected
+    monkeypatch.setenv("LRT_NO_TORCH_INIT", "1")
+    assert _lib._pytorch_context_first() == "skipped"

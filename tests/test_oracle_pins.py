@@ -594,3 +594,25 @@ def test_volpathmis_matches_volpath_on_a_lit_scene(mi, orc, tmp_path):
         means[name] = img.mean((0, 1))
     assert np.allclose(means["mis"], means["volpath"], rtol=0.03), means
     assert np.allclose(means["mis-nospectral"], means["volpath"], rtol=0.03), means
+
+
+def test_oracle_native_flags_build_gives_the_same_lanes(tmp_path, mi, orc, liver_small):
+    """bench.py times the oracle's scalar renderer built with -O3 -march=native on the host it runs on: with -ffp-contract=off and no
+    fast-math that build computes the same binary32 values as the shipped -O2 -mfma one (lanes and scalar-renderer film bit for bit)."""
+    import subprocess
+    from conftest import ROOT
+    native = os.path.join(str(tmp_path), "liborc_native.so")
+    src = [os.path.join(ROOT, "oracle", f) for f in ("orc_scene.cpp", "orc_render.cpp", "orc_api.cpp", "orc_vae.cpp")]
+    subprocess.run(["g++", "-O3", "-march=native", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-pthread", "-shared", "-o", native] + src, check=True)
+    n = 128 * 72 * 4
+    a = orc.OrcScene(liver_small).render_samples(0, n, seed=2)
+    ra = orc.OrcScene(liver_small).render(scalar=True, spp=2, seed=1, threads=4)
+    shipped = orc.ORC_LIB
+    try:
+        orc.use_library(native)
+        b = orc.OrcScene(liver_small).render_samples(0, n, seed=2)
+        rb = orc.OrcScene(liver_small).render(scalar=True, spp=2, seed=1, threads=4)
+    finally:
+        orc.use_library(shipped)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert np.allclose(ra, rb, rtol=1e-5, atol=1e-7)          # (the block renderer's film sums in thread-completion order)

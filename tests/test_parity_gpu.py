@@ -138,26 +138,7 @@ def test_parenchyma_and_multimesh_scenes_bit_exact(mi, orc):
     assert_lanes_equal(sc, orc.OrcScene(sc), 0, 160 * 90 * sc.spp)
 
 
-def fog_xml(md="12", rf="gaussian", sensor_medium="", exterior="", env=""):
-    return f"""<scene version="3.0.0">
-  <integrator type="volpath"><integer name="max_depth" value="{md}"/></integrator>
-  <medium type="homogeneous" id="fog"><rgb name="sigma_t" value="1.5, 0.7, 2.0"/><rgb name="albedo" value="0.9, 0.95, 0.6"/>
-    <phase type="hg"><float name="g" value="0.5"/></phase></medium>
-  <medium type="homogeneous" id="haze"><float name="sigma_t" value="0.05"/><float name="albedo" value="0.8"/>
-    <boolean name="has_spectral_extinction" value="false"/></medium>
-  <sensor type="perspective"><float name="fov" value="40"/>
-    <transform name="to_world"><lookat origin="3, 2.5, 4" target="0, 0, 0" up="0, 1, 0"/></transform>
-    <sampler type="independent"><integer name="sample_count" value="32"/></sampler>
-    <film type="hdrfilm"><integer name="width" value="64"/><integer name="height" value="48"/><rfilter type="{rf}"/></film>
-    {sensor_medium}
-  </sensor>
-  <shape type="cube"><bsdf type="null"/><ref name="interior" id="fog"/>{exterior}</shape>
-  <shape type="rectangle"><transform name="to_world"><scale value="6"/><rotate x="1" angle="-90"/><translate y="-1.001"/></transform>
-    <bsdf type="diffuse"><texture name="reflectance" type="checkerboard"><transform name="to_uv"><scale x="8" y="8"/></transform></texture></bsdf>{exterior}</shape>
-  <shape type="rectangle"><transform name="to_world"><scale value="0.7"/><rotate x="1" angle="90"/><translate y="3.5"/></transform>
-    <emitter type="area"><rgb name="radiance" value="20, 18, 15"/></emitter>{exterior}</shape>
-  {env}
-</scene>"""
+from scene_gen import fog_xml  # noqa: E402  (shared with bench.py)
 
 
 @pytest.mark.parametrize("variant", ["null_boundary", "camera_in_medium", "constant_env"])

@@ -48,6 +48,9 @@ def test_backward_per_medium(mi, orc):
     assert np.abs(res[0]["sigma_t"]).max() > 0 and np.abs(res[1]["sigma_t"]).max() > 0 and res[1]["g"] == 0.0   # haze is isotropic
     for k in ("sigma_t", "albedo"):
         assert np.allclose(res[0][k] + res[1][k], res[-1][k], rtol=2e-3, atol=1e-7)
+    dflt = sc.render_backward(grad, seed=4)                            # the Python default is the sum over all media
+    for k in ("sigma_t", "albedo"):
+        assert np.allclose(dflt[k], res[-1][k], rtol=2e-3, atol=1e-7)
     with pytest.raises(RuntimeError, match="grad_medium"):
         sc.render_backward(grad, medium=2)
 
@@ -111,28 +114,7 @@ def test_liver_singlemesh_bio_reference_render(mi):
     assert np.abs(img - g)[inner].mean() < 0.08 * g[inner].mean()
 
 
-def het_xml(vol, sampler="independent", spectral="true", boundary="null", extra_medium="", inside_ref="smoke", md=12):
-    return f"""<scene version="3.0.0">
-  <integrator type="volpath"><integer name="max_depth" value="{md}"/></integrator>
-  <medium type="heterogeneous" id="smoke">
-    <volume name="sigma_t" type="gridvolume"><string name="filename" value="{vol}"/>
-      <transform name="to_world"><scale value="2"/><translate x="-1" y="-1" z="-1"/></transform></volume>
-    <rgb name="albedo" value="0.9, 0.8, 0.6"/><float name="scale" value="3"/><boolean name="has_spectral_extinction" value="{spectral}"/>
-    <phase type="hg"><float name="g" value="0.3"/></phase>
-  </medium>
-  {extra_medium}
-  <sensor type="perspective"><float name="fov" value="40"/>
-    <transform name="to_world"><lookat origin="3, 2.5, 4" target="0, 0, 0" up="0, 1, 0"/></transform>
-    <sampler type="{sampler}"><integer name="sample_count" value="16"/></sampler>
-    <film type="hdrfilm"><integer name="width" value="64"/><integer name="height" value="48"/><rfilter type="box"/></film>
-  </sensor>
-  <shape type="cube"><bsdf type="{boundary}"/><ref name="interior" id="{inside_ref}"/></shape>
-  <shape type="rectangle"><transform name="to_world"><scale value="6"/><rotate x="1" angle="-90"/><translate y="-1.001"/></transform>
-    <bsdf type="diffuse"><texture name="reflectance" type="checkerboard"><transform name="to_uv"><scale x="8" y="8"/></transform></texture></bsdf></shape>
-  <shape type="rectangle"><transform name="to_world"><scale value="0.7"/><rotate x="1" angle="90"/><translate y="3.5"/></transform>
-    <emitter type="area"><rgb name="radiance" value="20, 18, 15"/></emitter></shape>
-  <emitter type="constant"><rgb name="radiance" value="0.3, 0.4, 0.6"/></emitter>
-</scene>"""
+from scene_gen import het_xml  # noqa: E402  (shared with bench.py)
 
 
 @pytest.mark.parametrize("case", ["null", "dielectric-ld", "nonspectral", "two-media"])
