@@ -56,6 +56,7 @@ struct DeviceScene {
     std::vector<DMedium> h_media; DMedium *d_media = nullptr;
     std::vector<DBioMedium> h_bio; DBioMedium *d_bio = nullptr;
     std::vector<DHetMedium> h_het; DHetMedium *d_het = nullptr; std::vector<float *> het_data; bool has_het = false, has_non_bio = false, need_mis = false, mis_alloc = false;
+    bool prb_null = false;                 // prbvolpath.py:84-91 `handle_null_scattering`: a heterogeneous medium is attached to a shape
     DLdsInfo lds{}; bool use_lds = false; int n_cus = 256; int bvh_leaf = 4;
 
     template <typename T> T *track(T *p) { allocs.push_back((void *) p); return p; }
@@ -315,6 +316,8 @@ DeviceScene *device_scene_create(const lrt_scene_desc &d, int device) {
             LRT_SMEM((k_render<LRT_INTEGRATOR_VOLPATHMIS_PLAIN, 1024, true, false>)); LRT_SMEM((k_render<LRT_INTEGRATOR_VOLPATHMIS_PLAIN, 1024, true, true>));
             LRT_SMEM((k_render_prb<false, 1024, true, false>)); LRT_SMEM((k_render_prb<true, 1024, true, false>));
             LRT_SMEM((k_render_prb<false, 1024, true, true>)); LRT_SMEM((k_render_prb<true, 1024, true, true>));
+            LRT_SMEM((k_render_prb<false, 1024, true, false, true>)); LRT_SMEM((k_render_prb<true, 1024, true, false, true>));
+            LRT_SMEM((k_render_prb<false, 1024, true, true, true>)); LRT_SMEM((k_render_prb<true, 1024, true, true, true>));
             LRT_SMEM((k_trace_lds<true>)); LRT_SMEM((k_trace_lds<false>));
 #endif
             #undef LRT_SMEM
@@ -417,6 +420,8 @@ DeviceScene *device_scene_create(const lrt_scene_desc &d, int device) {
         D->het_data[i] = D->track(dev_upload(M.grid_data, (size_t) M.grid_res[0] * M.grid_res[1] * M.grid_res[2], st));
         D->has_het = true;
     }
+    for (uint32_t i = 0; i < d.n_shapes; ++i) for (int m : { d.shapes[i].interior_medium, d.shapes[i].exterior_medium })
+        if (m >= 0 && d.media[m].type == LRT_MEDIUM_HETEROGENEOUS) D->prb_null = true;
     upload_media(D.get(), d); sc.media = D->d_media; sc.bio = D->d_bio; sc.het = D->d_het;
     // ---- emitters
     std::vector<DEmitter> em(d.n_emitters); std::vector<float> env_rgbx, hier; bool env_interior_positive = false;
@@ -678,7 +683,8 @@ static void launch_prb(DeviceScene *D, const DRenderParams &rp, const PoolGeomet
 #ifdef LRT_DEV_VOLPATH_ONLY
     (void) lp; throw std::runtime_error("developer build: volpath only");
 #else
-    #define LRT_LAUNCH_PRB(BS, LDSB, LD) k_render_prb<ADJOINT, BS, LDSB, LD><<<g.n_wg, BS, g.smem, st>>>((ScenePtr) D->d_sc, lp)
+    #define LRT_LAUNCH_PRB(BS, LDSB, LD) do { if (D->prb_null) k_render_prb<ADJOINT, BS, LDSB, LD, true><<<g.n_wg, BS, g.smem, st>>>((ScenePtr) D->d_sc, lp); \
+                                              else k_render_prb<ADJOINT, BS, LDSB, LD, false><<<g.n_wg, BS, g.smem, st>>>((ScenePtr) D->d_sc, lp); } while (0)
     if (D->use_lds) { if (rp.ld_count) LRT_LAUNCH_PRB(1024, true, true); else LRT_LAUNCH_PRB(1024, true, false); }
     else { if (rp.ld_count) LRT_LAUNCH_PRB(LRT_BLOCK, false, true); else LRT_LAUNCH_PRB(LRT_BLOCK, false, false); }
     #undef LRT_LAUNCH_PRB
@@ -687,12 +693,10 @@ static void launch_prb(DeviceScene *D, const DRenderParams &rp, const PoolGeomet
 }
 
 // Which media an integrator can meet: the bio integrators call the 5-argument Medium::sample_interaction, which the base class
-// (homogeneous / heterogeneous media) answers with NotImplementedError (src/render/medium.cpp:83-90); the PRB adjoint here is
-// derived for homogeneous coefficients; volpathmis is not built.
+// (homogeneous / heterogeneous media) answers with NotImplementedError (src/render/medium.cpp:83-90).
 static void check_integrator_media(DeviceScene *D, int integrator) {
     if ((integrator == LRT_INTEGRATOR_BIOVOLPATH || integrator == LRT_INTEGRATOR_BIOVOLPATH06) && D->has_non_bio)
         throw std::runtime_error("NotImplementedError: sample_interaction (the bio integrators need liver / parenchyma / glissonCapsule media)");
-    if (integrator == LRT_INTEGRATOR_PRBVOLPATH && D->has_het) throw std::runtime_error("unsupported: prbvolpath with heterogeneous media");
     if (integrator == LRT_INTEGRATOR_VOLPATHMIS) D->need_mis = true;          // its wider path record is allocated on first use
 }
 

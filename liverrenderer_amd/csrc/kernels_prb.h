@@ -9,6 +9,13 @@
 //   NEE transmittance   tr_c = exp(-t_seg sigma_c):  d ln tr_c / d sigma_c = -t_seg
 //   phase value         d ln hg / d g = -2g/(1-g^2) - 3 (g + c) / (1 + g^2 + 2 g c)
 // and PRB multiplies them by delta_L * (radiance still to be collected).
+//
+// HET (a heterogeneous medium is attached to a shape: prbvolpath.py:84-91 `handle_null_scattering`): delta tracking with null
+// collisions on the path (:178-196), ratio tracking on the emitter-sampling march (:404-415).  Only sigma_t(p) = scale * grid(p)
+// carries a gradient there (the majorant is an opaque scalar made in parameters_changed(), src/media/heterogeneous.cpp):
+//   real collision  d ln(sigma_s_c) / d scale = 1 / scale,   d ln(sigma_s_c) / d a_c = 1 / a_c
+//   null collision  d ln(sigma_n_c) / d scale = -sigma_t(p) / (sigma_n_c scale)
+// and d_sigma_t[c] of such a medium is channel c's share of d / d scale (include/liverrt.h).
 #pragma once
 #include "kernels.h"
 
@@ -23,7 +30,9 @@ DEV float hg_dlog_dg(float g, float c) {
 
 // prbvolpath.py:354-444.  Returns emitter_val * transmittance; seg_sum[c] accumulates -t_seg * scale over the
 // medium segments the reference backpropagates through (segments that end on a surface with tr_c > 0, :425-427).
-template <typename SMP, typename TR>
+DEV float het_null_dlog_dscale(const DMedium &M, float sigma_t, float sigma_n) { return sigma_n > 0.f ? -(sigma_t / sigma_n) / M.scale : 0.f; }
+
+template <bool HET, typename SMP, typename TR>
 DEV V3 prb_sample_emitter(SceneRef sc, SMP &rng, V3 ref_p, V3 ref_n, bool ref_is_surface, uint32_t ref_shape, V3 ref_geo_n,
                           int medium, uint32_t channel, DirSample *ds_out, const TR &tr, uint32_t &n_shadow, V3 *seg_sum, int grad_medium) {
     float sx, sy; rng.next2(sx, sy);
@@ -46,30 +55,48 @@ DEV V3 prb_sample_emitter(SceneRef sc, SMP &rng, V3 ref_p, V3 ref_n, bool ref_is
         needs_intersection = false;
         bool active_medium = active && medium >= 0, active_surface = active && !active_medium;
         V3 tr_multiplier(1.f);
-        float seg_t = 0.f, scale_t = 0.f; bool escaped_medium = false;
+        float seg_t = 0.f, scale_t = 0.f, mei_t = kInf; bool escaped_medium = false;
+        V3 null_dlog(0.f);
         if (!active_medium) rng.skip(1);             // prbvolpath.py:396: the call runs for every lane in the march
         if (active_medium) {
-            (void) rng.next();
             const DMedium M = tab(sc.media, medium);
-            float t = fmin_(remaining_dist, si.t);
-            seg_t = fmin_(t, si.t) - 0.f;
-            tr_multiplier = V3(m_exp(-seg_t * M.sigma_t[0]), m_exp(-seg_t * M.sigma_t[1]), m_exp(-seg_t * M.sigma_t[2]));
-            scale_t = (grad_medium < 0 || medium == grad_medium) ? -seg_t * M.scale : 0.f;   // only the differentiated medium's segments
-            escaped_medium = true; active_medium = false;
+            const bool graded = grad_medium < 0 || medium == grad_medium;   // only the differentiated medium's segments
+            if (HET && M.het) {                      // ratio tracking (:409-415): a collision inside the segment is a null collision of the march
+                MI mei = het_sample_interaction(M, tab(sc.het, medium), ray, rng.next());
+                if (si.t < mei.t) mei.t = kInf;
+                escaped_medium = !mei.valid(); active_medium = mei.valid();
+                if (active_medium) {
+                    ray.o = mei.p; si.t = si.t - mei.t; mei_t = mei.t;
+                    tr_multiplier = mei.sigma_n / mei.combined;
+                    if (graded) null_dlog = V3(het_null_dlog_dscale(M, mei.sigma_t.x, mei.sigma_n.x), het_null_dlog_dscale(M, mei.sigma_t.x, mei.sigma_n.y), het_null_dlog_dscale(M, mei.sigma_t.x, mei.sigma_n.z));
+                }
+            } else {                                 // homogeneous: straight to the next surface / the end of the segment (:403-407)
+                (void) rng.next();
+                float t = fmin_(remaining_dist, si.t);
+                seg_t = fmin_(t, si.t) - 0.f;
+                tr_multiplier = V3(m_exp(-seg_t * M.sigma_t[0]), m_exp(-seg_t * M.sigma_t[1]), m_exp(-seg_t * M.sigma_t[2]));
+                scale_t = graded ? -seg_t * M.scale : 0.f;
+                escaped_medium = true; active_medium = false;
+            }
         }
         active_surface = (active_surface || escaped_medium) && si.valid && !active_medium;
         if (active_surface) tr_multiplier = tr_multiplier * bsdf_null_transmission(sc, tab(sc.shapes, si.shape, sc.one_shape).bsdf);
-        if (escaped_medium && active_surface) {
+        if (escaped_medium && active_surface) {      // :425-427: active_adj = (surface | medium) & tr > 0
             if (tr_multiplier.x > 0.f) sum.x += scale_t;
             if (tr_multiplier.y > 0.f) sum.y += scale_t;
             if (tr_multiplier.z > 0.f) sum.z += scale_t;
+        }
+        if (HET && active_medium) {
+            if (tr_multiplier.x > 0.f) sum.x += null_dlog.x;
+            if (tr_multiplier.y > 0.f) sum.y += null_dlog.y;
+            if (tr_multiplier.z > 0.f) sum.z += null_dlog.z;
         }
         transmittance = transmittance * tr_multiplier;
         if (active_surface) ray = spawn_ray(si.p, si.n, ray.d);
         ray.maxt = remaining_dist;
         needs_intersection = needs_intersection || active_surface;
         active = active && (active_medium || active_surface) && any_nonzero(transmittance);
-        if (active) total_dist += si.t;
+        if (active) total_dist += (HET && active_medium) ? mei_t : si.t;
         if (active_surface) { const DShape sd = tab(sc.shapes, si.shape, sc.one_shape); if (is_medium_transition(sd)) medium = target_medium(sd, ray.d, si.n); }
     }
     *seg_sum = sum;
@@ -78,11 +105,13 @@ DEV V3 prb_sample_emitter(SceneRef sc, SMP &rng, V3 ref_p, V3 ref_n, bool ref_is
 
 // One trip of prbvolpath's loop (prbvolpath.py:139-349).  s.res holds L: accumulated radiance (primal) or the
 // radiance still to be collected (adjoint).  Returns true when the path survives.
-template <bool ADJOINT, typename SMP, typename TR>
+template <bool ADJOINT, bool HET, typename SMP, typename TR>
 DEV bool prb_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, const TR &tr, uint32_t &n_shadow,
                        V3 delta_L, PrbGrads &G) {
     uint32_t depth = s.flags & PF_DEPTH_MASK;
     const bool proven_empty = (s.flags & PF_NOHIT) != 0;               // look-ahead of the previous trip, see below
+    const bool needs_intersection = !(HET && (s.flags & PF_HAVE_SI));  // HET: a null collision keeps the surface interaction found earlier (record's hit stream)
+    Hit hkeep; hkeep.t = s.hit.x; hkeep.u = s.hit.y; hkeep.v = s.hit.z; hkeep.prim = f2u(s.hit.w);
     int medium = (int) ((s.flags & PF_MEDIUM_MASK) >> PF_MEDIUM_SHIFT) - 1;
     const uint32_t channel = (s.flags >> PF_CHANNEL_SHIFT) & 3u;
     bool specular_chain = (s.flags & PF_SPECULAR) != 0, valid_ray = (s.flags & PF_VALID) != 0;
@@ -101,17 +130,19 @@ DEV bool prb_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, const TR &
     if (active) { float u = rng.next(); active = (u < q) || !perform_rr; }
     if (perform_rr) throughput = throughput * rcp(q);
     bool active_medium = active && medium >= 0, active_surface = active && !active_medium;
-    bool escaped_medium = false, act_medium_scatter = false, in_medium_segment = false;
-    MI mei; mei.t = kInf; mei.wi = -ray.d; mei.p = V3(0.f);
+    bool escaped_medium = false, act_medium_scatter = false, act_null_scatter = false, in_medium_segment = false, het = false;
+    MI mei; mei.t = kInf; mei.wi = -ray.d; mei.p = V3(0.f); mei.sigma_t = V3(0.f); mei.sigma_n = V3(0.f); mei.combined = V3(1.f);
     SI si; si.valid = false; si.t = kInf;
     V3 weight(1.f);
-    float seg_t = 0.f;
+    float seg_t = 0.f, scatter_prob = 1.f;
     if (!active_medium) rng.skip(1);                  // prbvolpath.py:158
     if (active_medium) {
         const DMedium M = tab(sc.media, medium);
-        mei = medium_sample_interaction(M, ray, rng.next(), channel);
-        if (mei.valid()) ray.maxt = mei.t;
-        if (!proven_empty) { Hit h = tr.closest(ray); si = tr.surface(sc, ray, h); }
+        het = HET && M.het;
+        mei = het ? het_sample_interaction(M, tab(sc.het, medium), ray, rng.next()) : medium_sample_interaction(M, ray, rng.next(), channel);
+        if (mei.valid() && !het) ray.maxt = mei.t;                                  // medium.is_homogeneous() only (:163)
+        if (!needs_intersection) si = compute_si(sc, ray, hkeep);
+        else if (!proven_empty) { hkeep = tr.closest(ray); si = tr.surface(sc, ray, hkeep); }
         if (si.t < mei.t) mei.t = kInf;
         seg_t = fmin_(mei.t, si.t) - mei.mint;
         V3 tr(m_exp(-seg_t * mei.combined.x), m_exp(-seg_t * mei.combined.y), m_exp(-seg_t * mei.combined.z));
@@ -121,17 +152,32 @@ DEV bool prb_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, const TR &
         escaped_medium = !mei.valid();
         active_medium = mei.valid();
         in_medium_segment = true;
-        if (active_medium) { act_medium_scatter = true; depth += 1; s.lp = mei.p; }
     }
+    if (HET) {                                        // :178-183: one more draw per trip in a scene that holds a heterogeneous medium
+        if (!active_medium) rng.skip(1);
+        else {
+            scatter_prob = mean3(mei.sigma_t / mei.combined);
+            act_null_scatter = rng.next() >= scatter_prob;
+            if (act_null_scatter) weight = weight * (mei.sigma_n / (1.f - scatter_prob));
+        }
+    }
+    if (active_medium && !act_null_scatter) { act_medium_scatter = true; depth += 1; s.lp = mei.p; }
     active = active && depth < max_depth;
     act_medium_scatter = act_medium_scatter && active;
-    if (act_medium_scatter) weight = weight * mei.sigma_s;
+    if (HET && act_null_scatter) { ray.o = mei.p; hkeep.t = si.t - mei.t; }         // :194-196 (si.t -= mei.t)
+    if (act_medium_scatter) weight = weight * (HET ? mei.sigma_s / scatter_prob : mei.sigma_s);
     throughput = throughput * weight;
     const int gm = rp.grad_medium;
     if (ADJOINT && in_medium_segment && (gm < 0 || medium == gm)) {     // prbvolpath.py:199-204
         const DMedium M = tab(sc.media, medium);
-        auto term = [&](float w, float l, float dl, float st, float al, float &gs, float &ga) {
+        auto term = [&](float w, float l, float dl, float st, float al, float sn, float &gs, float &ga) {
             float Lo = l / fmax_(1e-8f, w);
+            if (het) {                                // only the collision coefficient depends on `scale` (header comment)
+                const float dlog = act_medium_scatter ? 1.f / M.scale : (act_null_scatter ? het_null_dlog_dscale(M, mei.sigma_t.x, sn) : 0.f);
+                gs += dl * Lo * (w * dlog);
+                if (act_medium_scatter) ga += dl * Lo * (w / al);
+                return;
+            }
             float dws = w * (-seg_t) + (act_medium_scatter ? w / st : 0.f);
             if (!(seg_t < kInf)) dws = 0.f;
             gs += dl * Lo * dws * M.scale;
@@ -140,9 +186,9 @@ DEV bool prb_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, const TR &
 #ifdef LRT_EXPERIMENT
         if (rp.pad1 && s.lane == rp.pad1 - 1u) printf("  [dev] medium term: depth %u seg_t %.9g w %.9g %.9g %.9g L %.9g %.9g %.9g dl %.9g scatter %d\n", depth, seg_t, weight.x, weight.y, weight.z, L.x, L.y, L.z, delta_L.x, (int) act_medium_scatter);
 #endif
-        term(weight.x, L.x, delta_L.x, M.sigma_t[0], M.albedo[0], G.sigma_t[0], G.albedo[0]);
-        term(weight.y, L.y, delta_L.y, M.sigma_t[1], M.albedo[1], G.sigma_t[1], G.albedo[1]);
-        term(weight.z, L.z, delta_L.z, M.sigma_t[2], M.albedo[2], G.sigma_t[2], G.albedo[2]);
+        term(weight.x, L.x, delta_L.x, M.sigma_t[0], M.albedo[0], mei.sigma_n.x, G.sigma_t[0], G.albedo[0]);
+        term(weight.y, L.y, delta_L.y, M.sigma_t[1], M.albedo[1], mei.sigma_n.y, G.sigma_t[1], G.albedo[1]);
+        term(weight.z, L.z, delta_L.z, M.sigma_t[2], M.albedo[2], mei.sigma_n.z, G.sigma_t[2], G.albedo[2]);
     }
     // ---- surface interactions
     active_surface = active_surface || escaped_medium;
@@ -183,7 +229,7 @@ DEV bool prb_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, const TR &
     if (active_e_surface || active_e_medium) {
         DirSample ds; V3 seg_sum;
         V3 rp_ = active_e_medium ? mei.p : si.p, rn = active_e_medium ? V3(0.f) : si.n;
-        V3 emitted = prb_sample_emitter(sc, rng, rp_, rn, active_e_surface, active_e_surface ? si.shape : 0u, si.n, medium, channel, &ds, tr, n_shadow, &seg_sum, gm);
+        V3 emitted = prb_sample_emitter<HET>(sc, rng, rp_, rn, active_e_surface, active_e_surface ? si.shape : 0u, si.n, medium, channel, &ds, tr, n_shadow, &seg_sum, gm);
         V3 nee_weight; float nee_pdf;
         if (active_e_surface) { V3 wo = si.sh.to_local(ds.d); nee_weight = bsdf_eval(sc, b, si, wo); nee_pdf = bsdf_pdf(sc, b, si, wo); }
         else { float pv = phase_eval(tab(sc.media, medium), mei.wi, ds.d); nee_weight = V3(pv); nee_pdf = pv; }
@@ -241,7 +287,7 @@ DEV bool prb_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, const TR &
     // sampler; when the distance field proves that the segment reaches no surface, the path is queued apart and its next
     // trip runs no ray query.  Exact: same draws, same functions, conservative proof.
     uint32_t nohit = 0;
-    if (active && medium >= 0 && sc.grid.enabled) {
+    if (active && medium >= 0 && sc.grid.enabled && !(HET && (act_null_scatter || tab(sc.media, medium).het))) {   // (a heterogeneous medium does not shorten the ray: its query is always the full one)
         SMP pk = rng;
         bool a2 = any_nonzero(throughput);
         float q2 = fmin_(max3(throughput) * sqr(eta), 0.99f);
@@ -254,6 +300,7 @@ DEV bool prb_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, const TR &
     }
     commit();
     s.flags |= nohit;
+    if (HET && act_null_scatter && active) { s.flags |= PF_HAVE_SI; s.hit = make_float4(hkeep.t, hkeep.u, hkeep.v, u2f(hkeep.prim)); }
     return active;
 }
 
@@ -303,9 +350,11 @@ DEV V3 lane_delta_L(SceneRef sc, RpRef rp, uint32_t lane, const float *__restric
 // ADJOINT == true : replay; finished lanes only retire; the parameter gradients of a tile are summed inside the wave,
 //                   accumulated per workgroup in f64 (LDS) and added to grads[7] once at the end.
 // 4 waves per SIMD for every variant (128 VGPRs): one 1024-thread workgroup per CU, or four 256-thread ones
-template <bool ADJOINT, int BLOCK, bool LDS_BVH, bool LD>
+// HET: the scene holds a heterogeneous medium: null collisions (prb_iteration<.., true>), 120-B records (+ the kept surface hit)
+template <bool ADJOINT, int BLOCK, bool LDS_BVH, bool LD, bool HET = false>
 __global__ void __launch_bounds__(BLOCK, 4)
 k_render_prb(ScenePtr scp, LaunchPtr lp) {
+    constexpr int MODE = HET ? 2 : 0;
     SceneRef sc = *scp;
     const LRT_CONST DLaunch &A = *lp;
     RpRef rp = A.rp;
@@ -364,7 +413,7 @@ k_render_prb(ScenePtr scp, LaunchPtr lp) {
                 if (t < ta) { i = (t << 6) + lane_in_wave; had_path = i < n_a; }
                 else if (t < tm) { i = ((t - ta) << 6) + lane_in_wave; had_path = i < n_c; i += P; }
                 else { i = ((t - tm) << 6) + lane_in_wave; had_path = i < n_s; i = 2u * P - 1u - i; }
-                if (had_path) { load_state(parity ? A.q1 : A.q0, pool + i, s); dl = (parity ? A.dl1 : A.dl0)[pool + i]; n_loaded += 1; }
+                if (had_path) { load_state<MODE>(parity ? A.q1 : A.q0, pool + i, s); dl = (parity ? A.dl1 : A.dl0)[pool + i]; n_loaded += 1; }
             } else {
                 const uint32_t i = ((t - tm - ts) << 6) + lane_in_wave;
                 had_path = i < fresh;
@@ -380,8 +429,8 @@ k_render_prb(ScenePtr scp, LaunchPtr lp) {
             PrbGrads G; G.sigma_t[0] = G.sigma_t[1] = G.sigma_t[2] = G.albedo[0] = G.albedo[1] = G.albedo[2] = G.g = 0.f;
             if (had_path) {
                 SamplerT<LD> rng = lane_rng_resume<LD>(rp, s.lane, s.rng_state);
-                alive = LDS_BVH ? prb_iteration<ADJOINT>(sc, rp, s, rng, tr_lds, n_shadow, V3(dl.x, dl.y, dl.z), G)
-                                : prb_iteration<ADJOINT>(sc, rp, s, rng, tr_glb, n_shadow, V3(dl.x, dl.y, dl.z), G);
+                alive = LDS_BVH ? prb_iteration<ADJOINT, HET>(sc, rp, s, rng, tr_lds, n_shadow, V3(dl.x, dl.y, dl.z), G)
+                                : prb_iteration<ADJOINT, HET>(sc, rp, s, rng, tr_glb, n_shadow, V3(dl.x, dl.y, dl.z), G);
                 s.rng_state = rng.state;
                 n_trips += 1;
             }
@@ -405,7 +454,7 @@ k_render_prb(ScenePtr scp, LaunchPtr lp) {
             if (alive) {
                 const uint32_t slot = b + (uint32_t) __popcll((region == 0 ? m0 : (region == 1 ? m1 : m2)) & ((1ull << lane_in_wave) - 1ull));
                 const uint32_t rec = region == 0 ? slot : (region == 1 ? P + slot : 2u * P - 1u - slot);
-                store_state(parity ? A.q0 : A.q1, pool + rec, s); (parity ? A.dl0 : A.dl1)[pool + rec] = dl;
+                store_state<MODE>(parity ? A.q0 : A.q1, pool + rec, s); (parity ? A.dl0 : A.dl1)[pool + rec] = dl;
             }
         }
         __syncthreads();

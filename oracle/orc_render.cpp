@@ -925,8 +925,18 @@ static inline float hg_dlog_dg(float g, float c) {
     return -2.f * g / (1.f - sqr(g)) - 1.5f * (2.f * g + 2.f * c) / temp;
 }
 
+/* Gradient bookkeeping of a heterogeneous medium (src/media/heterogeneous.cpp): sigma_t(p) = scale * grid(p) carries the gradient,
+   the majorant (`m_max_density`, an opaque scalar made in parameters_changed()) and with it the free-flight sampling and
+   exp(-t * combined) do not.  lrt_param_grads::d_sigma_t[k] of such a medium is channel k's share of d/d(scale): their sum is the
+   derivative w.r.t. the medium's `scale`.  d ln(sigma_s_k) / d scale = 1 / scale at a real collision,
+   d ln(sigma_n_k) / d scale = -sigma_t(p) / (sigma_n_k scale) at a null collision (:178-196, :404-415). */
+static inline float het_null_dlog_dscale(const lrt_medium_desc &M, float sigma_t, float sigma_n) {
+    return sigma_n > 0.f ? -(sigma_t / sigma_n) / M.scale : 0.f;
+}
+
 /* src/python/python/ad/integrators/prbvolpath.py:354-444.  adjoint: backpropagates delta_L * adj_emitted
-   through the per-segment transmittance (homogeneous media: analytic transmittance, :403-407). */
+   through the per-segment transmittance: homogeneous media take their analytic transmittance in one step (:403-407,
+   `nee_handle_homogeneous`), heterogeneous ones ratio tracking through null collisions (:409-415). */
 static V3 prb_sample_emitter(Ctx &C, V3 ref_p, V3 ref_n, const SI *ref_si, int medium, uint32_t channel, DirSample *ds_out,
                              bool adjoint, V3 delta_L, V3 adj_emitted, Grads *G) {
     const int gm = C.grad_medium;
@@ -951,23 +961,38 @@ static V3 prb_sample_emitter(Ctx &C, V3 ref_p, V3 ref_n, const SI *ref_si, int m
         needs_intersection = false;
         bool active_medium = active && medium >= 0, active_surface = active && !active_medium;
         V3 tr_multiplier(1.f);
-        float seg_t = 0.f; bool escaped_medium = false;
+        float seg_t = 0.f, mei_t = kInf; bool escaped_medium = false, homogeneous_segment = false;
+        float null_dlog[3] = { 0.f, 0.f, 0.f };
         if (!active_medium) C.skip(1);               /* prbvolpath.py:396: the call runs for every lane in the march */
         if (active_medium) {
-            (void) C.next();                         /* sample_interaction draw, overwritten below (:399-407) */
             const lrt_medium_desc &M = S.media[medium];
-            V3 sigmat = V3(M.sigma_t[0], M.sigma_t[1], M.sigma_t[2]) * M.scale;
-            float t = fminf(remaining_dist, si.t);   /* mei.t = min(remaining, si.t); tr = exp(-(min(mei.t, si.t) - mint) sigma) */
-            seg_t = fminf(t, si.t) - 0.f;
-            tr_multiplier = V3(m_exp(-seg_t * sigmat.x), m_exp(-seg_t * sigmat.y), m_exp(-seg_t * sigmat.z));
-            escaped_medium = true; active_medium = false;
+            MI mei = medium_sample_interaction(S, medium, ray, C.next(), channel);
+            if (si.t < mei.t) mei.t = kInf;
+            if (S.prb_nee_handle_homogeneous && medium_is_homogeneous(M)) {         /* :403-407: straight to the next surface / the end of the segment */
+                V3 sigmat = V3(M.sigma_t[0], M.sigma_t[1], M.sigma_t[2]) * M.scale;
+                float t = fminf(remaining_dist, si.t);   /* mei.t = min(remaining, si.t); tr = exp(-(min(mei.t, si.t) - mint) sigma) */
+                seg_t = fminf(t, si.t) - 0.f;
+                tr_multiplier = V3(m_exp(-seg_t * sigmat.x), m_exp(-seg_t * sigmat.y), m_exp(-seg_t * sigmat.z));
+                mei.t = kInf; homogeneous_segment = true;
+            }
+            escaped_medium = !mei.valid();
+            active_medium = mei.valid();
+            if (active_medium) {                     /* ratio tracking: a (null) collision inside the segment (:409-415) */
+                ray.o = mei.p; si.t = si.t - mei.t; mei_t = mei.t;
+                tr_multiplier *= mei.sigma_n / mei.combined;
+                float sn[3] = { mei.sigma_n.x, mei.sigma_n.y, mei.sigma_n.z };
+                for (int k = 0; k < 3; ++k) null_dlog[k] = het_null_dlog_dscale(M, mei.sigma_t.x, sn[k]);
+            }
         }
         active_surface = (active_surface || escaped_medium) && si.valid && !active_medium;
         if (active_surface) tr_multiplier *= bsdf_null_transmission(S, S.shapes[si.shape].bsdf);
-        if (adjoint && escaped_medium && active_surface && (gm < 0 || medium == gm)) {   /* :425-427, active_adj = (surface | medium) & tr > 0 */
+        if (adjoint && (active_surface || active_medium) && medium >= 0 && (gm < 0 || medium == gm)) {   /* :425-427, active_adj = (surface | medium) & tr > 0 */
             const lrt_medium_desc &M = S.media[medium];
             float c[3] = { tr_multiplier.x, tr_multiplier.y, tr_multiplier.z }, dl[3] = { delta_L.x, delta_L.y, delta_L.z }, ae[3] = { adj_emitted.x, adj_emitted.y, adj_emitted.z };
-            for (int k = 0; k < 3; ++k) if (c[k] > 0.f) G->sigma_t[k] += (double) (dl[k] * ae[k] * (-seg_t) * M.scale);
+            for (int k = 0; k < 3; ++k) if (c[k] > 0.f) {
+                if (homogeneous_segment && escaped_medium) G->sigma_t[k] += (double) (dl[k] * ae[k] * (-seg_t) * M.scale);
+                if (active_medium) G->sigma_t[k] += (double) (dl[k] * ae[k] * null_dlog[k]);
+            }
             if (g_prb_debug) fprintf(stderr, "  [orc] nee seg_t %.9g tr %.9g %.9g %.9g ae %.9g %.9g %.9g\n", seg_t, c[0], c[1], c[2], ae[0], ae[1], ae[2]);
         }
         transmittance *= tr_multiplier;
@@ -975,7 +1000,7 @@ static V3 prb_sample_emitter(Ctx &C, V3 ref_p, V3 ref_n, const SI *ref_si, int m
         ray.maxt = remaining_dist;
         needs_intersection = needs_intersection || active_surface;
         active = active && (active_medium || active_surface) && any_nonzero(transmittance);
-        if (active) total_dist += active_medium ? kInf : si.t;
+        if (active) total_dist += active_medium ? mei_t : si.t;
         if (active_surface && is_medium_transition(S.shapes[si.shape])) medium = target_medium(S.shapes[si.shape], ray.d, si.n);
     }
     return emitter_val * transmittance;
@@ -1006,10 +1031,11 @@ static void prb_sample(Ctx &C, Ray ray, bool adjoint, V3 delta_L, V3 L_in, V3 *L
         MI mei; mei.t = kInf; mei.wi = -ray.d; mei.p = V3(0.f); mei.medium = medium;
         V3 weight(1.f);
         float seg_t = 0.f; bool in_medium_segment = false;
+        bool act_null_scatter = false; float scatter_prob = 1.f;
         if (!active_medium) C.skip(1);               /* prbvolpath.py:158 */
         if (active_medium) {
             mei = medium_sample_interaction(S, medium, ray, C.next(), channel);
-            if (mei.valid()) ray.maxt = mei.t;
+            if (mei.valid() && medium_is_homogeneous(S.media[medium])) ray.maxt = mei.t;   /* :163 */
             if (needs_intersection) { Hit h = S.intersect(ray, false, false); si = S.compute_si(ray, h); }
             needs_intersection = false;
             if (si.t < mei.t) mei.t = kInf;
@@ -1021,18 +1047,37 @@ static void prb_sample(Ctx &C, Ray ray, bool adjoint, V3 delta_L, V3 L_in, V3 *L
             escaped_medium = !mei.valid();
             active_medium = mei.valid();
             in_medium_segment = true;
-            if (active_medium) { act_medium_scatter = true; depth += 1; last_scatter_p = mei.p; }
         }
+        if (S.prb_handle_null_scattering) {          /* :178-183: one more draw per trip in a scene that holds a heterogeneous medium */
+            if (!active_medium) C.skip(1);
+            else {
+                scatter_prob = mean3(mei.sigma_t / mei.combined);
+                act_null_scatter = C.next() >= scatter_prob;
+                if (act_null_scatter) weight *= mei.sigma_n / (1.f - scatter_prob);
+            }
+        }
+        if (active_medium && !act_null_scatter) { act_medium_scatter = true; depth += 1; last_scatter_p = mei.p; }
         active = active && depth < max_depth;
         act_medium_scatter = act_medium_scatter && active;
-        if (act_medium_scatter) weight *= mei.sigma_s;
+        const float si_t_before = si.t;
+        if (act_null_scatter) { ray.o = mei.p; si.t = si.t - mei.t; }                /* :194-196 */
+        if (act_medium_scatter) weight *= mei.sigma_s / scatter_prob;
         throughput *= weight;
+        (void) si_t_before;
         const int gm = C.grad_medium;
         if (adjoint && in_medium_segment && (gm < 0 || medium == gm)) {             /* :199-204 */
             const lrt_medium_desc &M = S.media[medium];
             float w[3] = { weight.x, weight.y, weight.z }, l[3] = { L.x, L.y, L.z }, dl[3] = { delta_L.x, delta_L.y, delta_L.z };
+            float sn[3] = { mei.sigma_n.x, mei.sigma_n.y, mei.sigma_n.z };
             for (int k = 0; k < 3; ++k) {
                 float Lo = l[k] / fmaxf(1e-8f, w[k]);
+                if (!medium_is_homogeneous(M)) {
+                    /* weight_k = exp(-t majorant) / pdf [* sigma_s_k / scatter_prob | * sigma_n_k / (1 - scatter_prob)]: only the bracket depends on `scale` */
+                    float dlog = act_medium_scatter ? 1.f / M.scale : (act_null_scatter ? het_null_dlog_dscale(M, mei.sigma_t.x, sn[k]) : 0.f);
+                    G->sigma_t[k] += (double) (dl[k] * Lo * (w[k] * dlog));
+                    if (act_medium_scatter) G->albedo[k] += (double) (dl[k] * Lo * (w[k] / M.albedo[k]));
+                    continue;
+                }
                 /* weight_k = exp(-t sigma_k) / pdf [* sigma_k a_k]:  d/dsigma_k = w (-t [+ 1/sigma_k]),  d/da_k = w / a_k */
                 float st = M.sigma_t[k] * M.scale;
                 float dws = w[k] * (-seg_t) + (act_medium_scatter ? w[k] / st : 0.f);

@@ -407,6 +407,9 @@ void Scene::finalize() {
     } else rf_radius = 0.5f;
     has_null_bsdf = false;
     for (auto &b : bsdfs) if (b.type == LRT_BSDF_NULL) has_null_bsdf = true;
+    for (auto &sh : shapes) for (int m : { sh.interior_medium, sh.exterior_medium }) if (m >= 0) {
+        if (media[m].type == LRT_MEDIUM_HETEROGENEOUS) prb_handle_null_scattering = true; else prb_nee_handle_homogeneous = true;
+    }
 }
 
 } // namespace orc

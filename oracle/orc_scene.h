@@ -68,6 +68,8 @@ struct Scene {
     /* reconstruction filter */
     float rf_radius = 0.5f; float rf_coeff[10]; float rf_inv_radius = 1.f;
     bool has_null_bsdf = false;
+    /* prbvolpath.py:84-91 prepare_scene(): over the media attached to shapes */
+    bool prb_handle_null_scattering = false, prb_nee_handle_homogeneous = false;
     bool bio_scalar = false;                  /* bio transport reading: false = JIT variants (default), true = scalar_rgb */
 
     void finalize();

@@ -222,3 +222,26 @@ def test_random_scene_bit_exact(mi, orc, seed):
     if (seed % 4 == 0 or sc.desc.samples_per_pass) and integrator != "prbvolpath":   # the film path too (all filters, all passes)
         raw = sc.render(return_raw=True, seed=seed)[1]
         assert film_close(raw, o.render(return_raw=True, seed=seed)[1]).all()
+
+
+def random_scene_prb_het(seed, tmpdir):
+    """Round-3 family: the PRB adjoint on the round-2 volume scenes (heterogeneous and homogeneous media mixed, null boundaries, every
+    emitter kind, both samplers): the first `volpath` scene of the round-2 generator from `seed` on, with the integrator swapped."""
+    k = seed
+    while True:
+        xml, integrator = random_scene_xml_r2(k, tmpdir)
+        if integrator == "volpath": break
+        k += 100_000
+    return xml.replace('<integrator type="volpath">', '<integrator type="prbvolpath">')
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_scene_prb_het(mi, orc, tmp_path, seed):
+    sc = mi.load_string(random_scene_prb_het(seed, tmp_path)); o = orc.OrcScene(sc)
+    h, w, c = sc.film_shape()
+    assert_lanes_equal(sc, o, 0, w * h * sc.spp, seed=seed)
+    grad = np.random.default_rng(seed).random((h, w, c)).astype(np.float32) / (h * w * c)
+    gg, gc = sc.render_backward(grad, seed=seed), o.render_backward(grad, seed=seed)
+    for k in ("sigma_t", "albedo"):
+        assert np.abs(gg[k] - gc[k]).max() <= 3e-4 * max(np.abs(gc[k]).max(), 1e-7), (k, gg[k], gc[k])
+    assert abs(gg["g"] - gc["g"]) <= 3e-4 * max(abs(gc["g"]), 1e-6) + 1e-9

@@ -139,9 +139,36 @@ def test_heterogeneous_medium_bit_exact(mi, orc, tmp_path, case):
     raw = sc.render(return_raw=True, **kw)[1]
     assert film_close(raw, o.render(return_raw=True, **kw)[1]).all()
     if case == "null":
-        for integ in ("prbvolpath", "biovolpath"):
-            with pytest.raises(RuntimeError, match="heterogeneous|NotImplementedError"):
-                sc.render_samples(0, 64, integrator=integ)
+        with pytest.raises(RuntimeError, match="NotImplementedError"):       # the bio integrators need bio media (medium.cpp:83-90)
+            sc.render_samples(0, 64, integrator="biovolpath")
+
+
+@pytest.mark.parametrize("case", ["null", "dielectric-ld", "two-media"])
+def test_prb_through_heterogeneous_media(mi, orc, tmp_path, case):
+    """VERDICT r2 missing 1 / next 3: lrt_render_backward on scenes with a heterogeneous medium (prbvolpath.py:178-196 null collisions
+    on the path, :404-415 ratio tracking on the emitter march).  Primal lanes bit for bit against the oracle, gradients against the
+    oracle's (which test_oracle_pins.py pins by finite differences), two tile shards summing to the unsharded gradients."""
+    import scene_gen
+    vol = os.path.join(str(tmp_path), "smoke.vol"); mi.write_volume_grid(vol, scene_gen.smoke_grid())
+    kw = dict(seed=3)
+    if case == "null": xml = het_xml(vol, md=8)
+    elif case == "dielectric-ld": xml = het_xml(vol, sampler="ldsampler", boundary="dielectric", md=10); kw = dict(seed=1, rr_depth=2)
+    else: xml = scene_gen.two_media_xml(vol, hom='<medium type="homogeneous" id="fog"><rgb name="sigma_t" value="0.5, 0.3, 0.8"/><rgb name="albedo" value="0.8, 0.8, 0.9"/></medium>', md=8)
+    sc = mi.load_string(xml.replace('type="volpath"', 'type="prbvolpath"')); o = orc.OrcScene(sc)
+    h, w, c = sc.film_shape()
+    assert_lanes_equal(sc, o, 0, w * h * sc.spp, **kw)
+    grad = np.random.default_rng(11).random((h, w, c)).astype(np.float32) / (h * w * c)
+    media = (0, 1, -1) if case == "two-media" else (0,)
+    for m in media:
+        gg, gc = sc.render_backward(grad, medium=m, **kw), o.render_backward(grad, medium=m, **kw)
+        for k in ("sigma_t", "albedo"):
+            assert np.abs(gg[k] - gc[k]).max() <= 3e-4 * max(np.abs(gc[k]).max(), 1e-7), (case, m, k, gg[k], gc[k])
+        assert abs(gg["g"] - gc["g"]) <= 3e-4 * max(abs(gc["g"]), 1e-6) + 1e-9
+        assert np.abs(gg["sigma_t"]).max() > 0 and np.abs(gg["albedo"]).max() > 0
+    full = sc.render_backward(grad, medium=0, **kw)
+    parts = [sc.render_backward(grad, medium=0, tile_rank=r, tile_count=2, **kw) for r in (0, 1)]
+    for k in ("sigma_t", "albedo"):
+        assert np.allclose(parts[0][k] + parts[1][k], full[k], rtol=2e-3, atol=1e-7)
 
 
 @pytest.mark.parametrize("smis", ["true", "false"])
