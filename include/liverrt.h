@@ -225,7 +225,10 @@ typedef struct {
 } lrt_render_stats;
 
 typedef struct {
-    float d_sigma_t[3];
+    float d_sigma_t[3];       /* homogeneous medium: w.r.t. the `sigma_t` property (before `scale`), per channel.
+                                 heterogeneous medium [v104]: channel k's share of d / d(scale); the three add up to the derivative
+                                 w.r.t. the medium's `scale` (sigma_t(p) = scale * grid(p); the majorant is detached,
+                                 src/media/heterogeneous.cpp parameters_changed) */
     float d_albedo[3];
     float d_g;
 } lrt_param_grads;
@@ -264,9 +267,26 @@ LRT_API lrt_status lrt_render_samples(lrt_scene *scene, const lrt_render_opts *o
                                       uint64_t lane_begin, uint32_t n, float *out);
 
 /* PRB adjoint: d(sum(image * grad_image)) / d(sigma_t, albedo, g) of medium opts->grad_medium (the reference
- * differentiates whichever parameters have gradients enabled: one call per medium gives the same numbers). */
+ * differentiates whichever parameters have gradients enabled: one call per medium gives the same numbers).
+ * Homogeneous and [v104] heterogeneous media (null collisions, src/python/python/ad/integrators/prbvolpath.py:178-196,
+ * 404-415); the bio media are rejected (LRT_ERR_UNSUPPORTED): the reference's prbvolpath reads them as homogeneous. */
 LRT_API lrt_status lrt_render_backward(lrt_scene *scene, const lrt_render_opts *opts,
                                        const float *grad_image, lrt_param_grads *out);
+
+/* One process, several devices [v104] (SURVEY.md 8e through the C ABI; no reference counterpart: the reference renders on one device):
+ * device i of the list (device_ids, or 0 .. n_devices - 1 when NULL) renders the 32x32 tiles t with t % n_devices == i into its own
+ * full-size zeroed film with GLOBAL lane ids - one host thread and one stream per device -, ONE ncclAllReduce (RCCL, bound at run time
+ * from /opt/rocm/lib/librccl.so; LRT_RCCL_LIBRARY overrides) sums the films, the first device develops.  film_raw / image as in
+ * lrt_render (with output_on_device: pointers on the first device of the list).  The result is the image lrt_render gives (up to the
+ * order of the float sums).  opts->tile_rank / tile_count / device are ignored (must be unset).  A list that names ONE device several
+ * times is a rehearsal for boxes with a single GPU: the peers' films are added on that device, no collective runs.
+ * lrt_render_backward_multi: the same sharding for the PRB adjoint; the 7 gradient sums are reduced with one all-reduce.
+ * What the reference-side C++ plugin calls from SamplingIntegrator::render / render_backward
+ * (include/mitsuba/render/integrator.h:74, :253) to use a whole node without a second process. */
+LRT_API lrt_status lrt_render_multi(lrt_scene *scene, const lrt_render_opts *opts, int n_devices, const int *device_ids,
+                                    float *film_raw, float *image);
+LRT_API lrt_status lrt_render_backward_multi(lrt_scene *scene, const lrt_render_opts *opts, int n_devices, const int *device_ids,
+                                             const float *grad_image, lrt_param_grads *out);
 
 /* SoA ray queries (layout mirrors RayHit of src/render/scene_native.inl:135-142).
  * Miss: t = +inf, prim = 0xffffffff.  any_hit: only t (0 on hit, +inf on miss). */

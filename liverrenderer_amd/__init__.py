@@ -253,6 +253,26 @@ class Scene:
         _lib.check(self._lib.lrt_render(self._h, C.byref(o), raw.ctypes.data if return_raw else None, img.ctypes.data))
         return (img, raw) if return_raw else img
 
+    def render_multi(self, devices, spp=0, seed=0, integrator=None, max_depth=None, rr_depth=None, hide_emitters=None, return_raw=False):
+        """lrt_render_multi: one process, the image tile-sharded over `devices` (a list of HIP ordinals), films summed by one RCCL
+        all-reduce, developed on the first device.  Same image as render()."""
+        h, w, c = self.film_shape()
+        img = np.empty((h, w, c), dtype=np.float32)
+        raw = np.empty((h, w, self.raw_channels()), dtype=np.float32) if return_raw else None
+        o = make_opts(integrator, max_depth, rr_depth, hide_emitters, spp, seed)
+        ids = (C.c_int * len(devices))(*[int(d) for d in devices])
+        _lib.check(self._lib.lrt_render_multi(self._h, C.byref(o), len(devices), ids, raw.ctypes.data if return_raw else None, img.ctypes.data))
+        return (img, raw) if return_raw else img
+
+    def render_backward_multi(self, grad_image, devices, **kw):
+        """lrt_render_backward_multi: the PRB adjoint sharded over `devices`, gradients reduced with one all-reduce."""
+        g = np.ascontiguousarray(grad_image, dtype=np.float32)
+        o = make_opts(kw.get("integrator"), kw.get("max_depth"), kw.get("rr_depth"), kw.get("hide_emitters"), kw.get("spp", 0), kw.get("seed", 0), grad_medium=kw.get("medium", -1))
+        ids = (C.c_int * len(devices))(*[int(d) for d in devices])
+        out = _lib.ParamGrads()
+        _lib.check(self._lib.lrt_render_backward_multi(self._h, C.byref(o), len(devices), ids, g.ctypes.data, C.byref(out)))
+        return {"sigma_t": np.array(out.d_sigma_t[:], dtype=np.float32), "albedo": np.array(out.d_albedo[:], dtype=np.float32), "g": float(out.d_g)}
+
     def render_to_device(self, film_ptr, image_ptr=None, **kw):
         """Render into caller-provided DEVICE buffers (e.g. torch tensors' data_ptr())."""
         o = make_opts(kw.get("integrator"), kw.get("max_depth"), kw.get("rr_depth"), kw.get("hide_emitters"), kw.get("spp", 0),

@@ -28,7 +28,7 @@ static lrt_status fail(lrt_status st, const std::string &msg) { g_error = msg; r
 extern "C" {
 
 const char *lrt_last_error(void) { return g_error.c_str(); }
-int lrt_version(void) { return 103; }    // 1.2: bio media fields in lrt_medium_desc, biovolpath integrators, grad_medium in lrt_render_opts; 1.3: lrt_render_stats.lds_resident
+int lrt_version(void) { return 104; }    // 1.2: bio media fields in lrt_medium_desc, biovolpath integrators, grad_medium in lrt_render_opts; 1.3: lrt_render_stats.lds_resident; 1.4: lrt_render_multi / lrt_render_backward_multi, PRB through heterogeneous media
 
 static std::vector<std::pair<std::string, std::string>> parse_defines(const char *const *defines, int n) {
     std::vector<std::pair<std::string, std::string>> r;
@@ -139,10 +139,28 @@ lrt_status lrt_scene_from_desc(const lrt_scene_desc *desc, lrt_scene **out) {
 
 const lrt_scene_desc *lrt_scene_desc_get(const lrt_scene *scene) { return scene ? &scene->st.desc : nullptr; }
 
+static void multi_release(lrt_scene *s) {
+    if (s->multi_ctx) { multi_context_destroy(s->multi_ctx); s->multi_ctx = nullptr; }
+    for (auto *D : s->multi) device_scene_destroy(D);
+    s->multi.clear(); s->multi_ids.clear();
+}
+
 void lrt_scene_free(lrt_scene *scene) {
     if (!scene) return;
+    multi_release(scene);
     if (scene->dev) device_scene_destroy(scene->dev);
     delete scene;
+}
+
+// One device image per entry of the device list (device_ids == NULL: devices 0 .. n - 1), kept until another list is asked for.
+static void ensure_devices(lrt_scene *s, int n, const int *ids) {
+    if (n < 1 || n > 64) throw std::invalid_argument("lrt_render_multi: n_devices must be 1 .. 64");
+    std::vector<int> want(n); for (int i = 0; i < n; ++i) want[i] = ids ? ids[i] : i;
+    if (want != s->multi_ids) {
+        multi_release(s);
+        for (int dev : want) s->multi.push_back(device_scene_create(s->st.desc, dev));
+        s->multi_ids = want; s->multi_params_dirty = false;
+    } else if (s->multi_params_dirty) { for (auto *D : s->multi) device_scene_update_params(D, s->st.desc); s->multi_params_dirty = false; }
 }
 
 // device < 0: whatever device the image already lives on (0 when there is none yet).  A render that names another device
@@ -159,6 +177,26 @@ lrt_status lrt_render(lrt_scene *scene, const lrt_render_opts *opts, float *film
     LRT_TRY
         ensure_device(scene, opts ? opts->device : 0);
         device_render(scene->dev, scene->st.desc, opts, film_raw, image, scene->stats);
+        return LRT_OK;
+    LRT_CATCH
+}
+
+lrt_status lrt_render_multi(lrt_scene *scene, const lrt_render_opts *opts, int n_devices, const int *device_ids, float *film_raw, float *image) {
+    if (!scene) return fail(LRT_ERR_INVALID, "lrt_render_multi: null scene");
+    LRT_TRY
+        if (opts && (opts->tile_count > 1 || opts->tile_rank != 0)) throw std::invalid_argument("lrt_render_multi shards the image itself: tile_rank / tile_count must be 0 / 1 (or 0 / 0)");
+        ensure_devices(scene, n_devices, device_ids);
+        device_render_multi(scene->multi, scene->multi_ctx, scene->st.desc, opts, film_raw, image, scene->stats);
+        return LRT_OK;
+    LRT_CATCH
+}
+
+lrt_status lrt_render_backward_multi(lrt_scene *scene, const lrt_render_opts *opts, int n_devices, const int *device_ids, const float *grad_image, lrt_param_grads *out) {
+    if (!scene || !grad_image || !out) return fail(LRT_ERR_INVALID, "lrt_render_backward_multi: null argument");
+    LRT_TRY
+        if (opts && (opts->tile_count > 1 || opts->tile_rank != 0)) throw std::invalid_argument("lrt_render_backward_multi shards the image itself: tile_rank / tile_count must be 0 / 1 (or 0 / 0)");
+        ensure_devices(scene, n_devices, device_ids);
+        device_render_backward_multi(scene->multi, scene->multi_ctx, scene->st.desc, opts, grad_image, out, scene->stats);
         return LRT_OK;
     LRT_CATCH
 }
@@ -238,7 +276,7 @@ lrt_status lrt_param_set(lrt_scene *scene, const char *key, const float *v, int 
         if (M->phase != LRT_PHASE_HG && v[0] == 0.f) return fail(LRT_ERR_INVALID, std::string("unknown parameter \"") + key + "\" (the medium's phase function is isotropic)");
         M->g = v[0]; M->phase = LRT_PHASE_HG;
     } else return fail(LRT_ERR_INVALID, std::string("unknown parameter \"") + key + "\"");
-    scene->params_dirty = true;
+    scene->params_dirty = true; scene->multi_params_dirty = true;
     return LRT_OK;
 }
 

@@ -14,6 +14,11 @@
 #include <string>
 #include <cstdio>
 #include <cstdlib>
+#include <thread>
+#include <chrono>
+#include <exception>
+#include <dlfcn.h>
+#include <rccl/rccl.h>      // types and enums only: the functions are bound with dlopen (librccl.so is not a link-time dependency)
 
 namespace lrt {
 
@@ -1003,6 +1008,145 @@ void device_vae_scatter(const float *blob, uint32_t n, const float *in_pos, cons
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipMemcpy(out_pos, d_opos.p, 3 * (size_t) n * sizeof(float), hipMemcpyDeviceToHost));
     HIP_CHECK(hipMemcpy(out_absorption, d_oabs.p, (size_t) n * sizeof(float), hipMemcpyDeviceToHost));
+}
+
+// ------------------------------------------------------------------ one process, several devices (include/liverrt.h: lrt_render_multi)
+// SURVEY.md 8e through the C ABI: device i renders the 32x32 tiles t with t % N == i into its own full-size zeroed film (global lane
+// ids), ONE ncclAllReduce (RCCL over xGMI, sum, f32, H*W*C) merges the films, device 0 develops.  One host thread and one stream per
+// device.  RCCL is bound at run time from /opt/rocm/lib/librccl.so (LRT_RCCL_LIBRARY overrides): the library that matches the HIP
+// runtime libliverrt.so links, whatever copy another framework in the process carries.
+struct Rccl {
+    void *h = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr; ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    void load() {
+        if (h) return;
+        const char *env = getenv("LRT_RCCL_LIBRARY");
+        for (const char *name : { env ? env : "/opt/rocm/lib/librccl.so", "librccl.so.1", "librccl.so" }) { h = dlopen(name, RTLD_NOW | RTLD_LOCAL); if (h) break; }
+        if (!h) throw std::runtime_error(std::string("hip: cannot load librccl.so (") + (dlerror() ? dlerror() : "?") + "); lrt_render_multi on distinct devices needs RCCL");
+        auto sym = [&](const char *n) { void *p = dlsym(h, n); if (!p) throw std::runtime_error(std::string("hip: librccl.so lacks ") + n); return p; };
+        CommInitAll = (decltype(CommInitAll)) sym("ncclCommInitAll"); AllReduce = (decltype(AllReduce)) sym("ncclAllReduce");
+        GroupStart = (decltype(GroupStart)) sym("ncclGroupStart"); GroupEnd = (decltype(GroupEnd)) sym("ncclGroupEnd");
+        CommDestroy = (decltype(CommDestroy)) sym("ncclCommDestroy"); GetErrorString = (decltype(GetErrorString)) sym("ncclGetErrorString");
+    }
+    void check(ncclResult_t r, const char *what) { if (r != ncclSuccess) throw std::runtime_error(std::string("hip: rccl ") + what + ": " + (GetErrorString ? GetErrorString(r) : "error")); }
+};
+static Rccl g_rccl;
+
+struct MultiContext {                     // the communicators of one device list (ncclCommInitAll takes about a second: kept with the scene)
+    std::vector<int> devices; std::vector<ncclComm_t> comms;
+    ~MultiContext() { for (auto c : comms) if (c && g_rccl.CommDestroy) (void) g_rccl.CommDestroy(c); }
+};
+void multi_context_destroy(MultiContext *m) { delete m; }
+
+__global__ void k_film_add(float *__restrict__ dst, const float *__restrict__ src, size_t n) {
+    const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] += src[i];
+}
+
+static float *own_film(DeviceScene *D, size_t film_floats) {
+    if (D->film_floats < film_floats) { D->release(D->film); D->film = nullptr; HIP_CHECK(hipMalloc((void **) &D->film, film_floats * 4)); D->track(D->film); D->film_floats = film_floats; }
+    return D->film;
+}
+
+// Sums buf[i] (`count` floats or doubles on device i, stream of device i) over the devices, in place.  Distinct devices: one grouped
+// ncclAllReduce.  The same device named several times (a rehearsal on a one-GPU box): the peers share the device, so rank 0's buffer
+// takes the others' with a kernel and nothing crosses a link.
+template <typename T>
+static void reduce_across(std::vector<DeviceScene *> &devs, MultiContext *&ctx, std::vector<T *> &buf, size_t count) {
+    const int N = (int) devs.size();
+    bool distinct = true;
+    for (int i = 0; i < N; ++i) for (int j = 0; j < i; ++j) if (devs[i]->device == devs[j]->device) distinct = false;
+    for (auto *D : devs) { HIP_CHECK(hipSetDevice(D->device)); HIP_CHECK(hipStreamSynchronize(D->stream)); }
+    if (distinct) {
+        g_rccl.load();
+        std::vector<int> ids; for (auto *D : devs) ids.push_back(D->device);
+        if (!ctx || ctx->devices != ids) {
+            delete ctx; ctx = new MultiContext(); ctx->devices = ids; ctx->comms.assign(N, nullptr);
+            g_rccl.check(g_rccl.CommInitAll(ctx->comms.data(), N, ids.data()), "ncclCommInitAll");
+        }
+        g_rccl.check(g_rccl.GroupStart(), "ncclGroupStart");
+        for (int i = 0; i < N; ++i) {
+            HIP_CHECK(hipSetDevice(devs[i]->device));
+            g_rccl.check(g_rccl.AllReduce(buf[i], buf[i], count, sizeof(T) == 8 ? ncclDouble : ncclFloat, ncclSum, ctx->comms[i], devs[i]->stream), "ncclAllReduce");
+        }
+        g_rccl.check(g_rccl.GroupEnd(), "ncclGroupEnd");
+        for (auto *D : devs) { HIP_CHECK(hipSetDevice(D->device)); HIP_CHECK(hipStreamSynchronize(D->stream)); }
+    } else {
+        for (int i = 1; i < N; ++i) if (devs[i]->device != devs[0]->device) throw std::runtime_error("lrt_render_multi: a device list is either all distinct or one device repeated");
+        static_assert(sizeof(T) == 4 || sizeof(T) == 8, "float or double");
+        HIP_CHECK(hipSetDevice(devs[0]->device));
+        for (int i = 1; i < N; ++i) {
+            if (sizeof(T) == 4) k_film_add<<<(uint32_t) ((count + 255) / 256), 256, 0, devs[0]->stream>>>((float *) buf[0], (const float *) buf[i], count);
+            else { std::vector<double> a(count), b(count); HIP_CHECK(hipMemcpy(a.data(), buf[0], count * 8, hipMemcpyDeviceToHost)); HIP_CHECK(hipMemcpy(b.data(), buf[i], count * 8, hipMemcpyDeviceToHost));
+                   for (size_t k = 0; k < count; ++k) a[k] += b[k]; HIP_CHECK(hipMemcpy(buf[0], a.data(), count * 8, hipMemcpyHostToDevice)); }
+        }
+        HIP_CHECK(hipGetLastError()); HIP_CHECK(hipStreamSynchronize(devs[0]->stream));
+    }
+}
+
+template <typename F> static void on_every_device(size_t n, F fn) {
+    std::vector<std::exception_ptr> err(n);
+    std::vector<std::thread> th;
+    for (size_t i = 0; i < n; ++i) th.emplace_back([&, i]() { try { fn(i); } catch (...) { err[i] = std::current_exception(); } });
+    for (auto &t : th) t.join();
+    for (auto &e : err) if (e) std::rethrow_exception(e);
+}
+
+void device_render_multi(std::vector<DeviceScene *> &devs, MultiContext *&ctx, const lrt_scene_desc &d, const lrt_render_opts *opts, float *film_raw, float *image, lrt_render_stats &stats) {
+    const int N = (int) devs.size();
+    const DFilm &F = devs[0]->sc.film;
+    const size_t np = (size_t) F.width * F.height, film_floats = np * F.channels, image_floats = np * (F.has_alpha ? 4 : 3);
+    const bool on_device = opts && opts->output_on_device;                     // film_raw / image then live on the FIRST device of the list
+    std::vector<float *> films(N); std::vector<lrt_render_stats> st(N);
+    const auto t0 = std::chrono::steady_clock::now();
+    on_every_device(N, [&](size_t i) {
+        HIP_CHECK(hipSetDevice(devs[i]->device));
+        films[i] = (i == 0 && on_device && film_raw) ? film_raw : own_film(devs[i], film_floats);
+        lrt_render_opts o = opts ? *opts : lrt_render_opts{ -1, -2, -1, -1, 0, 0, 0, 1, 0, 0, 0, 0 };
+        o.tile_rank = (uint32_t) i; o.tile_count = (uint32_t) N; o.device = devs[i]->device; o.output_on_device = 1;
+        device_render(devs[i], d, &o, films[i], nullptr, st[i]);
+    });
+    if (N > 1 || getenv("LRT_MULTI_ALWAYS_REDUCE")) reduce_across(devs, ctx, films, film_floats);
+    DeviceScene *D0 = devs[0];
+    HIP_CHECK(hipSetDevice(D0->device));
+    if (image) {
+        float *img = image;
+        if (!on_device) { if (D0->image_floats < image_floats) { D0->release(D0->image); D0->image = nullptr; HIP_CHECK(hipMalloc((void **) &D0->image, image_floats * 4)); D0->track(D0->image); D0->image_floats = image_floats; } img = D0->image; }
+        k_develop<<<(uint32_t) ((np + 255) / 256), 256, 0, D0->stream>>>(F, films[0], img, (uint32_t) np);
+        if (!on_device) HIP_CHECK(hipMemcpyAsync(image, img, image_floats * 4, hipMemcpyDeviceToHost, D0->stream));
+    }
+    if (film_raw && !on_device) HIP_CHECK(hipMemcpyAsync(film_raw, films[0], film_floats * 4, hipMemcpyDeviceToHost, D0->stream));
+    HIP_CHECK(hipStreamSynchronize(D0->stream)); HIP_CHECK(hipGetLastError());
+    lrt_render_stats total{};
+    for (auto &x : st) { total.n_samples += x.n_samples; total.n_iter += x.n_iter; total.n_shadow += x.n_shadow; total.n_launches += x.n_launches; total.n_records += x.n_records;
+                         total.kernel_ms = std::max(total.kernel_ms, x.kernel_ms); total.lds_resident = x.lds_resident; }
+    total.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    stats = total;
+}
+
+void device_render_backward_multi(std::vector<DeviceScene *> &devs, MultiContext *&ctx, const lrt_scene_desc &d, const lrt_render_opts *opts, const float *grad_image, lrt_param_grads *out, lrt_render_stats &stats) {
+    const int N = (int) devs.size();
+    if (opts && opts->output_on_device) throw std::runtime_error("lrt_render_backward_multi: grad_image is a host buffer (every device takes its own copy)");
+    std::vector<lrt_param_grads> g(N); std::vector<lrt_render_stats> st(N);
+    on_every_device(N, [&](size_t i) {
+        lrt_render_opts o = opts ? *opts : lrt_render_opts{ -1, -2, -1, -1, 0, 0, 0, 1, 0, 0, 0, 0 };
+        o.tile_rank = (uint32_t) i; o.tile_count = (uint32_t) N; o.device = devs[i]->device; o.output_on_device = 0;
+        device_render_backward(devs[i], d, &o, grad_image, &g[i], st[i]);
+    });
+    // the 7 gradient doubles of every device (still in its d_grads) are reduced like the film: one all-reduce
+    std::vector<double *> bufs; for (auto *D : devs) bufs.push_back(D->d_grads);
+    if (N > 1) reduce_across(devs, ctx, bufs, 7);
+    double h[7]; HIP_CHECK(hipSetDevice(devs[0]->device)); HIP_CHECK(hipMemcpy(h, devs[0]->d_grads, sizeof(h), hipMemcpyDeviceToHost));
+    for (int k = 0; k < 3; ++k) { out->d_sigma_t[k] = (float) h[k]; out->d_albedo[k] = (float) h[3 + k]; }
+    out->d_g = (float) h[6];
+    lrt_render_stats total{};
+    for (auto &x : st) { total.n_samples += x.n_samples; total.n_iter += x.n_iter; total.n_shadow += x.n_shadow; total.n_launches += x.n_launches; total.n_records += x.n_records;
+                         total.kernel_ms = std::max(total.kernel_ms, x.kernel_ms); total.total_ms = std::max(total.total_ms, x.total_ms); total.lds_resident = x.lds_resident; }
+    stats = total;
 }
 
 } // namespace lrt

@@ -2,6 +2,7 @@
 // translation unit (device.hip).  All functions throw std::runtime_error.
 #pragma once
 #include "../../include/liverrt.h"
+#include <vector>
 
 namespace lrt {
 struct DeviceScene;
@@ -16,4 +17,9 @@ void device_trace(DeviceScene *D, const lrt_rays_soa *rays, const lrt_hits_soa *
 void device_vae_scatter(const float *blob, uint32_t n, const float *in_pos, const float *in_dir, const float *poly, const float albedo[3], float g, float ior,
                         const float sigma_t[3], float fit_scale, uint32_t seed, float *out_pos, float *out_absorption, int device);
 void device_render_backward(DeviceScene *D, const lrt_scene_desc &d, const lrt_render_opts *opts, const float *grad_image, lrt_param_grads *out, lrt_render_stats &stats);
+// one process, several devices: tiles over the devices, one RCCL all-reduce of the film / of the 7 gradient doubles (device.hip)
+struct MultiContext;
+void multi_context_destroy(MultiContext *m);
+void device_render_multi(std::vector<DeviceScene *> &devs, MultiContext *&ctx, const lrt_scene_desc &d, const lrt_render_opts *opts, float *film_raw, float *image, lrt_render_stats &stats);
+void device_render_backward_multi(std::vector<DeviceScene *> &devs, MultiContext *&ctx, const lrt_scene_desc &d, const lrt_render_opts *opts, const float *grad_image, lrt_param_grads *out, lrt_render_stats &stats);
 } // namespace lrt

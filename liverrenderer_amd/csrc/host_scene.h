@@ -8,6 +8,7 @@
 namespace lrt {
 
 struct DeviceScene;   // device-resident data + wavefront workspace (device.hip)
+struct MultiContext;  // RCCL communicators of a device list (device.hip)
 
 // Owns every array the POD description points into.
 struct SceneStorage {
@@ -38,4 +39,6 @@ struct lrt_scene {
     bool params_dirty = true;
     int dev_ordinal = -1;                  // HIP device the device image lives on
     lrt_render_stats stats{};
+    // lrt_render_multi: one device image per entry of the last device list, and that list's communicators
+    std::vector<lrt::DeviceScene *> multi; std::vector<int> multi_ids; lrt::MultiContext *multi_ctx = nullptr; bool multi_params_dirty = false;
 };
