@@ -288,6 +288,11 @@ LRT_API lrt_status lrt_render_multi(lrt_scene *scene, const lrt_render_opts *opt
 LRT_API lrt_status lrt_render_backward_multi(lrt_scene *scene, const lrt_render_opts *opts, int n_devices, const int *device_ids,
                                              const float *grad_image, lrt_param_grads *out);
 
+/* Test hook [v104]: the device's own log / exp / sincos / atan2 / acos / log2 kernels (csrc/dmath.h: the arithmetic every path value
+ * goes through, standing in for Dr.Jit's dr::log / dr::exp / ... of include/mitsuba/core/math.h users) and its division / sqrt / rcp,
+ * one value per lane.  fn: 0 log(x), 1 exp(x), 2 sincos(x) -> out, out2, 3 atan2(y, x), 4 acos(x), 5 log2(x), 6 x / y, 7 sqrt(x), 8 1 / x. */
+LRT_API lrt_status lrt_math_eval(int fn, const float *x, const float *y, uint32_t n, float *out, float *out2, int device);
+
 /* SoA ray queries (layout mirrors RayHit of src/render/scene_native.inl:135-142).
  * Miss: t = +inf, prim = 0xffffffff.  any_hit: only t (0 on hit, +inf on miss). */
 typedef struct { const float *ox, *oy, *oz, *dx, *dy, *dz, *tmax; } lrt_rays_soa;

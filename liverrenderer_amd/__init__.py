@@ -336,6 +336,16 @@ class Scene:
         return v
 
 
+def math_eval(fn, x, y=None, device=0):
+    """lrt_math_eval (test hook): the device's transcendental kernels, one value per lane.  Returns (out, out2)."""
+    L = _lib.lib()
+    x = np.ascontiguousarray(x, np.float32); y = x if y is None else np.ascontiguousarray(y, np.float32)
+    out = np.empty_like(x); out2 = np.empty_like(x)
+    FP = C.POINTER(C.c_float)
+    _lib.check(L.lrt_math_eval(int(fn), x.ctypes.data_as(FP), y.ctypes.data_as(FP), x.size, out.ctypes.data_as(FP), out2.ctypes.data_as(FP), int(device)))
+    return out, out2
+
+
 class SceneParameters(dict):
     """mi.traverse(scene): dict of differentiable medium parameters; assignments are pushed by update()."""
 

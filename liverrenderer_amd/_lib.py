@@ -162,6 +162,7 @@ def lib():
     L.lrt_render.argtypes = [C.c_void_p, P(RenderOpts), C.c_void_p, C.c_void_p]
     L.lrt_render_multi.argtypes = [C.c_void_p, P(RenderOpts), C.c_int, P(C.c_int), C.c_void_p, C.c_void_p]
     L.lrt_render_backward_multi.argtypes = [C.c_void_p, P(RenderOpts), C.c_int, P(C.c_int), C.c_void_p, P(ParamGrads)]
+    L.lrt_math_eval.argtypes = [C.c_int, P(C.c_float), P(C.c_float), C.c_uint32, P(C.c_float), P(C.c_float), C.c_int]
     L.lrt_render_stats_get.argtypes = [C.c_void_p, P(RenderStats)]
     L.lrt_film_develop.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     L.lrt_render_samples.argtypes = [C.c_void_p, P(RenderOpts), C.c_uint64, C.c_uint32, C.c_void_p]
@@ -174,7 +175,7 @@ def lib():
     L.lrt_image_free.restype = None
     L.lrt_image_write_exr.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
     L.lrt_image_write_png.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
-    for name in ("lrt_image_read", "lrt_image_write_exr", "lrt_image_write_png", "lrt_scene_load_xml", "lrt_scene_load_xml_string", "lrt_scene_from_desc", "lrt_render", "lrt_render_multi", "lrt_render_backward_multi", "lrt_render_stats_get",
+    for name in ("lrt_image_read", "lrt_image_write_exr", "lrt_image_write_png", "lrt_scene_load_xml", "lrt_scene_load_xml_string", "lrt_scene_from_desc", "lrt_render", "lrt_render_multi", "lrt_render_backward_multi", "lrt_math_eval", "lrt_render_stats_get",
                  "lrt_film_develop", "lrt_render_samples", "lrt_render_backward", "lrt_trace", "lrt_param_set", "lrt_param_get"):
         getattr(L, name).restype = C.c_int
     _lib = L
@@ -182,7 +183,7 @@ def lib():
 
 
 EXPORTED_SYMBOLS = ["lrt_last_error", "lrt_version", "lrt_scene_load_xml", "lrt_scene_load_xml_string", "lrt_scene_from_desc",
-                    "lrt_scene_desc_get", "lrt_scene_free", "lrt_render", "lrt_render_multi", "lrt_render_backward_multi", "lrt_render_stats_get", "lrt_film_develop",
+                    "lrt_scene_desc_get", "lrt_scene_free", "lrt_render", "lrt_render_multi", "lrt_render_backward_multi", "lrt_math_eval", "lrt_render_stats_get", "lrt_film_develop",
                     "lrt_render_samples", "lrt_render_backward", "lrt_trace", "lrt_param_set", "lrt_param_get",
                     "lrt_image_read", "lrt_image_free", "lrt_image_write_exr", "lrt_image_write_png",
                     "lrt_vae_model_create", "lrt_vae_model_free", "lrt_vae_scatter"]

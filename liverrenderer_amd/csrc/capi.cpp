@@ -201,6 +201,14 @@ lrt_status lrt_render_backward_multi(lrt_scene *scene, const lrt_render_opts *op
     LRT_CATCH
 }
 
+lrt_status lrt_math_eval(int fn, const float *x, const float *y, uint32_t n, float *out, float *out2, int device) {
+    if (!x || !out) return fail(LRT_ERR_INVALID, "lrt_math_eval: null argument");
+    LRT_TRY
+        device_math_eval(fn, x, y, n, out, out2, device);
+        return LRT_OK;
+    LRT_CATCH
+}
+
 lrt_status lrt_render_stats_get(const lrt_scene *scene, lrt_render_stats *out) {
     if (!scene || !out) return fail(LRT_ERR_INVALID, "lrt_render_stats_get: null argument");
     *out = scene->stats; return LRT_OK;

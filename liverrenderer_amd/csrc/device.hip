@@ -1149,4 +1149,41 @@ void device_render_backward_multi(std::vector<DeviceScene *> &devs, MultiContext
     stats = total;
 }
 
+// Test hook (include/liverrt.h lrt_math_eval): the transcendental kernels of csrc/dmath.h evaluated on the device, one lane per value.
+// orc_math.h holds the same polynomials written a second time, so bit-equality of the render lanes says nothing about their accuracy:
+// tests/test_parity_gpu.py bounds the DEVICE values against float64 and checks them bit for bit against the oracle's twins.
+__global__ void k_math_eval(int fn, const float *__restrict__ x, const float *__restrict__ y, uint32_t n, float *__restrict__ out, float *__restrict__ out2) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float a = 0.f, b = 0.f;
+    switch (fn) {
+        case 0: a = m_log(x[i]); break;
+        case 1: a = m_exp(x[i]); break;
+        case 2: m_sincos(x[i], &a, &b); break;
+        case 3: a = m_atan2(y[i], x[i]); break;
+        case 4: a = m_acos(x[i]); break;
+        case 5: a = m_log2(x[i]); break;
+        case 6: a = x[i] / y[i]; break;
+        case 7: a = __builtin_sqrtf(x[i]); break;
+        case 8: a = rcp(x[i]); break;
+        default: break;
+    }
+    out[i] = a; out2[i] = b;
+}
+void device_math_eval(int fn, const float *x, const float *y, uint32_t n, float *out, float *out2, int device) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count == 0) throw std::runtime_error("no HIP device available: the hip_ad_rgb back-end has no CPU fallback");
+    if (device < 0 || device >= count) throw std::runtime_error("invalid HIP device ordinal " + std::to_string(device));
+    if (fn < 0 || fn > 8) throw std::invalid_argument("lrt_math_eval: function 0 .. 8");
+    HIP_CHECK(hipSetDevice(device));
+    if (!n) return;
+    struct Tmp { float *p = nullptr; ~Tmp() { if (p) (void) hipFree(p); } } dx, dy, d1, d2;
+    for (Tmp *t : { &dx, &dy, &d1, &d2 }) HIP_CHECK(hipMalloc((void **) &t->p, (size_t) n * 4));
+    HIP_CHECK(hipMemcpy(dx.p, x, (size_t) n * 4, hipMemcpyHostToDevice)); HIP_CHECK(hipMemcpy(dy.p, y ? y : x, (size_t) n * 4, hipMemcpyHostToDevice));
+    k_math_eval<<<(n + 255) / 256, 256>>>(fn, dx.p, dy.p, n, d1.p, d2.p);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipMemcpy(out, d1.p, (size_t) n * 4, hipMemcpyDeviceToHost));
+    if (out2) HIP_CHECK(hipMemcpy(out2, d2.p, (size_t) n * 4, hipMemcpyDeviceToHost));
+}
+
 } // namespace lrt

@@ -17,6 +17,7 @@ void device_trace(DeviceScene *D, const lrt_rays_soa *rays, const lrt_hits_soa *
 void device_vae_scatter(const float *blob, uint32_t n, const float *in_pos, const float *in_dir, const float *poly, const float albedo[3], float g, float ior,
                         const float sigma_t[3], float fit_scale, uint32_t seed, float *out_pos, float *out_absorption, int device);
 void device_render_backward(DeviceScene *D, const lrt_scene_desc &d, const lrt_render_opts *opts, const float *grad_image, lrt_param_grads *out, lrt_render_stats &stats);
+void device_math_eval(int fn, const float *x, const float *y, uint32_t n, float *out, float *out2, int device);   // test hook: dmath.h on the device
 // one process, several devices: tiles over the devices, one RCCL all-reduce of the film / of the 7 gradient doubles (device.hip)
 struct MultiContext;
 void multi_context_destroy(MultiContext *m);

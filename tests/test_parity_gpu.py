@@ -522,3 +522,35 @@ def test_prb_parenchyma_config5_geometry(mi, orc):
     for k in ("sigma_t", "albedo"):
         assert np.abs(gg[k] - gc[k]).max() <= 5e-4 * np.abs(gc[k]).max(), (k, gg[k], gc[k])
     assert np.abs(gc["albedo"]).max() > 0
+
+
+def test_device_math_kernels_accuracy_and_twins(mi, orc):
+    """csrc/dmath.h and oracle/orc_math.h are the same polynomial kernels written twice, so the bit-identity
+    of render lanes says nothing about their closeness to the functions Dr.Jit evaluates.  Here the DEVICE kernels are bounded against
+    float64 (the bounds of test_oracle_pins.py::test_math_kernels_accuracy) and compared bit for bit with the oracle's; division,
+    square root and reciprocal are checked to be correctly rounded (the reference's `/`, dr::sqrt, dr::rcp up to its own rcp
+    approximation)."""
+    from test_oracle_pins import _ulp_err
+    rng = np.random.default_rng(0)
+    def both(fn, x, y=None):
+        d = mi.math_eval(fn, x, y); c = orc.math_eval(fn, x, y)
+        assert np.array_equal(d[0].view(np.uint32), c[0].view(np.uint32)) and (fn != 2 or np.array_equal(d[1].view(np.uint32), c[1].view(np.uint32))), fn
+        return d
+    x = np.concatenate([1 - rng.random(200000), rng.random(200000) * 1e-3 + 1e-7, np.exp(rng.uniform(-80, 80, 100000))]).astype(np.float32)
+    assert _ulp_err(both(0, x)[0], np.log(x.astype(np.float64))).max() <= 2.0
+    assert _ulp_err(both(5, x)[0], np.log2(x.astype(np.float64))).max() <= 2.5
+    x = (-rng.random(400000) * 80).astype(np.float32)
+    assert _ulp_err(both(1, x)[0], np.exp(x.astype(np.float64))).max() <= 2.0
+    x = (rng.random(400000) * 2 * np.pi).astype(np.float32)
+    s, c = both(2, x)
+    assert np.abs(s - np.sin(x.astype(np.float64))).max() < 2e-7 and np.abs(c - np.cos(x.astype(np.float64))).max() < 2e-7
+    xx = rng.normal(size=400000).astype(np.float32); yy = rng.normal(size=400000).astype(np.float32)
+    assert np.abs(both(3, xx, yy)[0] - np.arctan2(yy.astype(np.float64), xx.astype(np.float64))).max() < 5e-7
+    x = (rng.random(400000) * 2 - 1).astype(np.float32)
+    assert np.abs(both(4, x)[0] - np.arccos(x.astype(np.float64))).max() < 5e-7
+    assert mi.math_eval(1, np.array([-200.0], np.float32))[0][0] == 0.0 and mi.math_eval(0, np.array([1.0], np.float32))[0][0] == 0.0
+    # IEEE: the device's division, square root and reciprocal are the correctly rounded ones (gfx950: -fhip-fp32-correctly-rounded-divide-sqrt default)
+    a = np.exp(rng.uniform(-40, 40, 400000)).astype(np.float32) * rng.choice([-1, 1], 400000).astype(np.float32); b = np.exp(rng.uniform(-40, 40, 400000)).astype(np.float32)
+    assert np.array_equal(mi.math_eval(6, a, b)[0].view(np.uint32), (a / b).view(np.uint32))
+    assert np.array_equal(mi.math_eval(7, b)[0].view(np.uint32), np.sqrt(b).view(np.uint32))
+    assert np.array_equal(mi.math_eval(8, b)[0].view(np.uint32), (np.float32(1) / b).view(np.uint32))
