@@ -309,8 +309,14 @@ DeviceScene *device_scene_create(const lrt_scene_desc &d, int device) {
             D->lds.blob_bytes = (uint32_t) blob.size(); D->lds.nodes_off = 0; D->lds.verts_off = (uint32_t) nodes_b; D->lds.tris_off = (uint32_t) (nodes_b + verts_b);
             D->lds.stack_off = (uint32_t) blob.size(); D->lds.total_bytes = (uint32_t) total;
             #define LRT_SMEM(K) HIP_CHECK(hipFuncSetAttribute((const void *) K, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_limit))
-#ifdef LRT_DEV_VOLPATH_ONLY                 // developer build (make dev): only the independent-sampler volpath kernel with the LDS BVH is compiled
-            LRT_SMEM((k_render<LRT_INTEGRATOR_VOLPATH, 1024, true, false>)); LRT_SMEM((k_trace_lds<true>)); LRT_SMEM((k_trace_lds<false>));
+#ifdef LRT_DEV_VOLPATH_ONLY                 // developer build (make dev): only ONE render kernel is compiled (default: volpath, independent sampler, LDS BVH;
+#ifndef LRT_DEV_INTEGRATOR                  // make dev DEVFLAGS="-DLRT_DEV_INTEGRATOR=LRT_INTEGRATOR_BIOVOLPATH -DLRT_DEV_LD=true" for another)
+#define LRT_DEV_INTEGRATOR LRT_INTEGRATOR_VOLPATH
+#endif
+#ifndef LRT_DEV_LD
+#define LRT_DEV_LD false
+#endif
+            LRT_SMEM((k_render<LRT_DEV_INTEGRATOR, 1024, true, LRT_DEV_LD>)); LRT_SMEM((k_trace_lds<true>)); LRT_SMEM((k_trace_lds<false>));
 #else
             LRT_SMEM((k_render<LRT_INTEGRATOR_PATH, 1024, true, false>)); LRT_SMEM((k_render<LRT_INTEGRATOR_VOLPATH, 1024, true, false>));
             LRT_SMEM((k_render<LRT_INTEGRATOR_PATH, 1024, true, true>)); LRT_SMEM((k_render<LRT_INTEGRATOR_VOLPATH, 1024, true, true>));
@@ -734,8 +740,8 @@ static void run_wavefront(DeviceScene *D, const lrt_scene_desc &d, const Resolve
         a.lane_begin = lane_begin; a.n = n_lanes; a.film = film; a.sample_out = sample_out; a.sample_base = lane_begin;
         const LaunchPtr lp = push_launch(D, a);
 #ifdef LRT_DEV_VOLPATH_ONLY
-        if (!(D->use_lds && O.integrator == LRT_INTEGRATOR_VOLPATH && !rp.ld_count && !D->has_het)) throw std::runtime_error("developer build: volpath / independent sampler / LDS BVH only");
-        k_render<LRT_INTEGRATOR_VOLPATH, 1024, true, false><<<g.n_wg, 1024, g.smem, st>>>((ScenePtr) D->d_sc, lp);
+        if (!(D->use_lds && O.integrator == LRT_DEV_INTEGRATOR && (rp.ld_count != 0) == LRT_DEV_LD && !D->has_het)) throw std::runtime_error("developer build: one integrator / sampler / LDS BVH only");
+        k_render<LRT_DEV_INTEGRATOR, 1024, true, LRT_DEV_LD><<<g.n_wg, 1024, g.smem, st>>>((ScenePtr) D->d_sc, lp);
         #define LRT_LAUNCH_I(BS, LDSB)
         #define LRT_LAUNCH(I, BS, LDSB)
 #else

@@ -781,7 +781,7 @@ k_render(ScenePtr scp, LaunchPtr lp) {
             if (had_path) {
                 SamplerT<LD> rng = lane_rng_resume<LD>(rp, s.lane, s.rng_state);
                 if (INTEGRATOR == LRT_INTEGRATOR_PATH) alive = LDS_BVH ? path_iteration(sc, rp, s, rng, tr_lds, n_shadow) : path_iteration(sc, rp, s, rng, tr_glb, n_shadow);
-                else if (INTEGRATOR == LRT_INTEGRATOR_BIOVOLPATH) alive = LDS_BVH ? biovolpath_iteration(sc, rp, s, rng, tr_lds, n_shadow, n_extra) : biovolpath_iteration(sc, rp, s, rng, tr_glb, n_shadow, n_extra);
+                else if (INTEGRATOR == LRT_INTEGRATOR_BIOVOLPATH) { const bool fresh_tile = t >= ta + tc + tb; alive = LDS_BVH ? biovolpath_iteration(sc, rp, s, rng, tr_lds, n_shadow, n_extra, fresh_tile) : biovolpath_iteration(sc, rp, s, rng, tr_glb, n_shadow, n_extra, fresh_tile); }
                 else if (INTEGRATOR == LRT_INTEGRATOR_BIOVOLPATH06) alive = LDS_BVH ? biovolpath06_iteration(sc, rp, s, rng, tr_lds) : biovolpath06_iteration(sc, rp, s, rng, tr_glb);
                 else if (INTEGRATOR == LRT_INTEGRATOR_VOLPATHMIS) alive = LDS_BVH ? volpathmis_iteration<true>(sc, rp, s, rng, tr_lds, n_shadow) : volpathmis_iteration<true>(sc, rp, s, rng, tr_glb, n_shadow);
                 else if (INTEGRATOR == LRT_INTEGRATOR_VOLPATHMIS_PLAIN) alive = LDS_BVH ? volpathmis_iteration<false>(sc, rp, s, rng, tr_lds, n_shadow) : volpathmis_iteration<false>(sc, rp, s, rng, tr_glb, n_shadow);

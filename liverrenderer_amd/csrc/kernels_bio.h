@@ -10,6 +10,10 @@
 
 namespace lrt {
 
+#ifndef LRT_BIO_GRID_STEPS
+#define LRT_BIO_GRID_STEPS LRT_GRID_STEPS      // sphere-tracing steps of biovolpath's free-flight stage (5 and 8 were measured: no gain on Liver-MultiMesh)
+#endif
+
 enum { BIO_ABSORBER = 0, BIO_ATTENUATOR = 1, BIO_ABSORBER_AND_ATTENUATOR = 2 };   // src/media/organic_material.h:29-34
 
 struct BioMI { float t; V3 p; V3 transmittance; V3 combined; DEV bool valid() const { return t != kInf; } };
@@ -151,34 +155,58 @@ DEV V3 bio_sample_emitter(SceneRef sc, SMP &rng, V3 ref_p, V3 ref_n, uint32_t re
 
 // One trip of biovolpath's while_loop (biovolpath.cpp:177-374), JIT-variant lane semantics.  s.si_t carries the distance
 // the previous trip's ray query returned (`Ray3f(ray, si.t)` at :226), s.tdepth the loop state `tissueDepth`.
+// As in volpath_iteration (kernels.h), the first stage of a trip - the termination test (:200-208) and, inside a medium, the free-flight
+// draw with its element competition (:226) - runs one trip early on the lane's own generator (`fresh`: at the start of a camera lane's
+// first trip): a queued record holds a path that is known to run its next trip, with the competition's outcome in the record.
 template <typename SMP, typename TR>
-DEV bool biovolpath_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, const TR &tr, uint32_t &n_shadow, uint32_t &n_extra) {
+DEV bool biovolpath_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, const TR &tr, uint32_t &n_shadow, uint32_t &n_extra, bool fresh = false) {
     uint32_t depth = s.flags & PF_DEPTH_MASK;
-    const bool proven_empty = (s.flags & PF_NOHIT) != 0;               // look-ahead of the previous trip (below)
+    bool proven_empty = (s.flags & PF_NOHIT) != 0;                     // the free-flight stage of the previous trip (below)
     int medium = (int) ((s.flags & PF_MEDIUM_MASK) >> PF_MEDIUM_SHIFT) - 1;
     const uint32_t channel = (s.flags >> PF_CHANNEL_SHIFT) & 3u;
     bool specular_chain = (s.flags & PF_SPECULAR) != 0, valid_ray = (s.flags & PF_VALID) != 0;
     const uint32_t max_depth = (uint32_t) rp.max_depth;
     V3 throughput = s.tp, result = s.res;
     float eta = s.eta, tissue_depth = s.tdepth, si_t = s.si_t;
+    float bio_dist = s.bio_dist; bool bio_hep = s.bio_hep;
     Ray ray; ray.o = s.o; ray.d = s.d; ray.maxt = s.maxt;
     auto commit = [&]() {
         s.tp = throughput; s.res = result; s.eta = eta; s.o = ray.o; s.d = ray.d; s.maxt = ray.maxt; s.tdepth = tissue_depth; s.si_t = si_t;
         s.flags = (depth & PF_DEPTH_MASK) | ((uint32_t) (medium + 1) << PF_MEDIUM_SHIFT) | (channel << PF_CHANNEL_SHIFT) |
                   (specular_chain ? PF_SPECULAR : 0u) | (valid_ray ? PF_VALID : 0u);
     };
-    // ---- termination (:200-208)
-    bool active = any_nonzero(throughput);
-    float q = fmin_(max3(throughput) * sqr(eta), .95f);
-    bool perform_rr = depth > (uint32_t) rp.rr_depth;
-    if (active) { float u = rng.next(); active = (u < q) || !perform_rr; }
-    if (perform_rr) throughput = throughput * rcp(q);
-    active = active && depth < max_depth;
-    if (!active) {
-        // the body still runs for this lane: its (masked) virtual call returns a zero `mei`, so :297-300 clears the result
-        result = V3(0.f);
-        commit(); return false;
+    // ---- termination (:200-208) of the trip about to run
+    auto termination_stage = [&]() -> bool {
+        bool a = any_nonzero(throughput);
+        const float q = fmin_(max3(throughput) * sqr(eta), .95f);
+        const bool perform_rr = depth > (uint32_t) rp.rr_depth;
+        if (a) { const float u = rng.next(); a = (u < q) || !perform_rr; }
+        if (perform_rr) throughput = throughput * rcp(q);
+        return a && depth < max_depth;
+    };
+    // inside a medium: the free-flight draw of the trip about to run, its element competition, and the attempt to prove the segment free
+    uint32_t nohit = 0;
+    float cache_dist = u2f(0x7fc00000u); bool cache_hep = false;
+    auto free_flight_stage = [&]() {
+        if (medium < 0) return;
+        int type2; float dist2;
+        bio_compute_distance(sc.bio[medium], channel, rng.next(), tissue_depth, type2, dist2);
+        if (sc.grid.enabled) {
+            const BioMI m2 = bio_finish_interaction<true>(sc.bio[medium], ray.o, ray.d, si_t, channel, type2, dist2);
+            if (m2.valid() && segment_proven_empty<LRT_BIO_GRID_STEPS>(sc.grid, ray.o, ray.d, m2.t)) nohit = PF_NOHIT;
+        }
+        cache_dist = dist2 == dist2 ? dist2 : kInf; cache_hep = type2 == BIO_ABSORBER_AND_ATTENUATOR;   // kept in the record: the next trip starts from it
+    };
+    if (fresh) {
+        if (!termination_stage()) {
+            // the body still runs for this lane: its (masked) virtual call returns a zero `mei`, so :297-300 clears the result
+            result = V3(0.f);
+            commit(); return false;
+        }
+        free_flight_stage(); bio_dist = cache_dist; bio_hep = cache_hep; proven_empty = nohit != 0;
+        nohit = 0; cache_dist = u2f(0x7fc00000u); cache_hep = false;
     }
+    bool active = true;
     bool active_medium = medium >= 0, active_surface = !active_medium;
     const bool in_medium_lane = active_medium;
     bool act_medium_scatter = false, escaped_medium = false;
@@ -187,10 +215,8 @@ DEV bool biovolpath_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, con
     if (!active_medium) rng.skip(2);                                    // :226, :244
     if (active_medium) {
         const DBioMedium &B = sc.bio[medium];
-        const float sample = rng.next();
-        if (s.bio_dist == s.bio_dist)                                   // the previous trip's look-ahead ran this competition (same sample, channel, depth)
-            mei = bio_finish_interaction<true>(B, ray.o, ray.d, si_t, channel, bio_cached_type(B, tissue_depth, s.bio_hep), s.bio_dist);
-        else mei = bio_sample_interaction<true>(B, ray.o, ray.d, si_t, sample, channel, tissue_depth);
+        // the free-flight stage ran this trip's competition (same sample, channel, depth)
+        mei = bio_finish_interaction<true>(B, ray.o, ray.d, si_t, channel, bio_cached_type(B, tissue_depth, bio_hep), bio_dist);
         if (mei.valid()) ray.maxt = mei.t;
         if (!proven_empty) { Hit h = tr.closest(ray); si = tr.surface(sc, ray, h); }   // else: no surface within mei.t, the query returns "none"
         si_t = si.t;
@@ -279,27 +305,13 @@ DEV bool biovolpath_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, con
         if (is_medium_transition(sd)) medium = target_medium(sd, ray.d, si.n);
     }
     active = active && (active_surface || active_medium);
-    // ---- look-ahead into the next trip, as in volpath_iteration (exact: the same draws on a copy of the generator).
-    // (1) A path the next trip's termination test would stop is retired now, with the cleared result that trip leaves
-    // (JIT reading of :200-208 + :297-300); the trip is counted in n_extra.  (2) In a medium the next free-flight sample is
-    // known: when the competition places an interaction inside the surface distance and the distance field proves the
-    // segment free of surfaces, the path is queued in region A and skips its ray query.
-    uint32_t nohit = 0;
-    float cache_dist = u2f(0x7fc00000u); bool cache_hep = false;
+    // ---- the first stage of the next trip, for real (see the top).  A path that stops there is retired now, with the cleared result that
+    // trip leaves (JIT reading of :200-208 + :297-300); the trip is counted in n_extra.  In a medium the next competition's outcome is then
+    // known: when it places an interaction inside the surface distance and the distance field proves the segment free of surfaces,
+    // the path is queued in region A and skips its ray query.
     if (active) {
-        SMP pk = rng;
-        bool a2 = any_nonzero(throughput);
-        float q2 = fmin_(max3(throughput) * sqr(eta), .95f);
-        if (a2) { float u = pk.next(); a2 = (u < q2) || !(depth > (uint32_t) rp.rr_depth); }
-        a2 = a2 && depth < max_depth;
-        if (!a2) { active = false; n_extra += 1; rng = pk; result = V3(0.f); }
-        else if (medium >= 0 && sc.grid.enabled) {
-            int type2; float dist2;
-            bio_compute_distance(sc.bio[medium], channel, pk.next(), tissue_depth, type2, dist2);
-            const BioMI m2 = bio_finish_interaction<true>(sc.bio[medium], ray.o, ray.d, si_t, channel, type2, dist2);
-            if (m2.valid() && segment_proven_empty(sc.grid, ray.o, ray.d, m2.t)) nohit = PF_NOHIT;
-            cache_dist = dist2 == dist2 ? dist2 : kInf; cache_hep = type2 == BIO_ABSORBER_AND_ATTENUATOR;   // kept in the record: the next trip starts from it
-        }
+        if (!termination_stage()) { active = false; n_extra += 1; result = V3(0.f); }
+        else free_flight_stage();
     }
     commit();
     s.flags |= nohit; s.bio_dist = cache_dist; s.bio_hep = cache_hep;
