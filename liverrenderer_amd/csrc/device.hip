@@ -32,6 +32,7 @@ template <typename T> static T *dev_upload(const T *src, size_t n, hipStream_t s
 }
 
 #define LRT_LAUNCH_SLOTS 64
+#define LRT_WIDE_BLOCK 768          // workgroup size of the render kernels with wide path records (volpathmis, volpath with heterogeneous media) on the LDS BVH
 
 struct DeviceScene {
     int device = 0;
@@ -316,15 +317,20 @@ DeviceScene *device_scene_create(const lrt_scene_desc &d, int device) {
 #ifndef LRT_DEV_LD
 #define LRT_DEV_LD false
 #endif
-            LRT_SMEM((k_render<LRT_DEV_INTEGRATOR, 1024, true, LRT_DEV_LD>)); LRT_SMEM((k_trace_lds<true>)); LRT_SMEM((k_trace_lds<false>));
+#ifndef LRT_DEV_BLOCK
+#define LRT_DEV_BLOCK 1024
+#endif
+            LRT_SMEM((k_render<LRT_DEV_INTEGRATOR, LRT_DEV_BLOCK, true, LRT_DEV_LD>)); LRT_SMEM((k_trace_lds<true>)); LRT_SMEM((k_trace_lds<false>));
 #else
             LRT_SMEM((k_render<LRT_INTEGRATOR_PATH, 1024, true, false>)); LRT_SMEM((k_render<LRT_INTEGRATOR_VOLPATH, 1024, true, false>));
             LRT_SMEM((k_render<LRT_INTEGRATOR_PATH, 1024, true, true>)); LRT_SMEM((k_render<LRT_INTEGRATOR_VOLPATH, 1024, true, true>));
             LRT_SMEM((k_render<LRT_INTEGRATOR_BIOVOLPATH, 1024, true, false>)); LRT_SMEM((k_render<LRT_INTEGRATOR_BIOVOLPATH, 1024, true, true>));
             LRT_SMEM((k_render<LRT_INTEGRATOR_BIOVOLPATH06, 1024, true, false>)); LRT_SMEM((k_render<LRT_INTEGRATOR_BIOVOLPATH06, 1024, true, true>));
-            LRT_SMEM((k_render<LRT_INTEGRATOR_VOLPATH_HET, 1024, true, false>)); LRT_SMEM((k_render<LRT_INTEGRATOR_VOLPATH_HET, 1024, true, true>));
-            LRT_SMEM((k_render<LRT_INTEGRATOR_VOLPATHMIS, 1024, true, false>)); LRT_SMEM((k_render<LRT_INTEGRATOR_VOLPATHMIS, 1024, true, true>));
-            LRT_SMEM((k_render<LRT_INTEGRATOR_VOLPATHMIS_PLAIN, 1024, true, false>)); LRT_SMEM((k_render<LRT_INTEGRATOR_VOLPATHMIS_PLAIN, 1024, true, true>));
+            // (the wide-record integrators run 768-thread workgroups: 3 waves per SIMD, 168 VGPRs instead of 128 + 200 - 430 B of scratch per lane;
+            //  measured on the f4 bench configs: volpathmis +58 %, volpath with heterogeneous media +9 %; 512 threads: +54 % / -18 %)
+            LRT_SMEM((k_render<LRT_INTEGRATOR_VOLPATH_HET, LRT_WIDE_BLOCK, true, false>)); LRT_SMEM((k_render<LRT_INTEGRATOR_VOLPATH_HET, LRT_WIDE_BLOCK, true, true>));
+            LRT_SMEM((k_render<LRT_INTEGRATOR_VOLPATHMIS, LRT_WIDE_BLOCK, true, false>)); LRT_SMEM((k_render<LRT_INTEGRATOR_VOLPATHMIS, LRT_WIDE_BLOCK, true, true>));
+            LRT_SMEM((k_render<LRT_INTEGRATOR_VOLPATHMIS_PLAIN, LRT_WIDE_BLOCK, true, false>)); LRT_SMEM((k_render<LRT_INTEGRATOR_VOLPATHMIS_PLAIN, LRT_WIDE_BLOCK, true, true>));
             LRT_SMEM((k_render_prb<false, 1024, true, false>)); LRT_SMEM((k_render_prb<true, 1024, true, false>));
             LRT_SMEM((k_render_prb<false, 1024, true, true>)); LRT_SMEM((k_render_prb<true, 1024, true, true>));
             LRT_SMEM((k_render_prb<false, 1024, true, false, true>)); LRT_SMEM((k_render_prb<true, 1024, true, false, true>));
@@ -740,8 +746,8 @@ static void run_wavefront(DeviceScene *D, const lrt_scene_desc &d, const Resolve
         a.lane_begin = lane_begin; a.n = n_lanes; a.film = film; a.sample_out = sample_out; a.sample_base = lane_begin;
         const LaunchPtr lp = push_launch(D, a);
 #ifdef LRT_DEV_VOLPATH_ONLY
-        if (!(D->use_lds && O.integrator == LRT_DEV_INTEGRATOR && (rp.ld_count != 0) == LRT_DEV_LD && !D->has_het)) throw std::runtime_error("developer build: one integrator / sampler / LDS BVH only");
-        k_render<LRT_DEV_INTEGRATOR, 1024, true, LRT_DEV_LD><<<g.n_wg, 1024, g.smem, st>>>((ScenePtr) D->d_sc, lp);
+        if (!(D->use_lds && (O.integrator == LRT_DEV_INTEGRATOR || (LRT_DEV_INTEGRATOR == LRT_INTEGRATOR_VOLPATH_HET && D->has_het)) && (rp.ld_count != 0) == LRT_DEV_LD)) throw std::runtime_error("developer build: one integrator / sampler / LDS BVH only");
+        k_render<LRT_DEV_INTEGRATOR, LRT_DEV_BLOCK, true, LRT_DEV_LD><<<g.n_wg, LRT_DEV_BLOCK, g.smem, st>>>((ScenePtr) D->d_sc, lp);
         #define LRT_LAUNCH_I(BS, LDSB)
         #define LRT_LAUNCH(I, BS, LDSB)
 #else
@@ -751,8 +757,8 @@ static void run_wavefront(DeviceScene *D, const lrt_scene_desc &d, const Resolve
             case LRT_INTEGRATOR_PATH: LRT_LAUNCH(LRT_INTEGRATOR_PATH, BS, LDSB); break; \
             case LRT_INTEGRATOR_BIOVOLPATH: LRT_LAUNCH(LRT_INTEGRATOR_BIOVOLPATH, BS, LDSB); break; \
             case LRT_INTEGRATOR_BIOVOLPATH06: LRT_LAUNCH(LRT_INTEGRATOR_BIOVOLPATH06, BS, LDSB); break; \
-            case LRT_INTEGRATOR_VOLPATHMIS: if (d.use_spectral_mis) LRT_LAUNCH(LRT_INTEGRATOR_VOLPATHMIS, BS, LDSB); else LRT_LAUNCH(LRT_INTEGRATOR_VOLPATHMIS_PLAIN, BS, LDSB); break; \
-            default: if (D->has_het) LRT_LAUNCH(LRT_INTEGRATOR_VOLPATH_HET, BS, LDSB); else LRT_LAUNCH(LRT_INTEGRATOR_VOLPATH, BS, LDSB); } } while (0)
+            case LRT_INTEGRATOR_VOLPATHMIS: if (d.use_spectral_mis) LRT_LAUNCH(LRT_INTEGRATOR_VOLPATHMIS, (LDSB ? LRT_WIDE_BLOCK : BS), LDSB); else LRT_LAUNCH(LRT_INTEGRATOR_VOLPATHMIS_PLAIN, (LDSB ? LRT_WIDE_BLOCK : BS), LDSB); break; \
+            default: if (D->has_het) LRT_LAUNCH(LRT_INTEGRATOR_VOLPATH_HET, (LDSB ? LRT_WIDE_BLOCK : BS), LDSB); else LRT_LAUNCH(LRT_INTEGRATOR_VOLPATH, BS, LDSB); } } while (0)
         if (D->use_lds) LRT_LAUNCH_I(1024, true); else LRT_LAUNCH_I(LRT_BLOCK, false);
 #endif
         #undef LRT_LAUNCH_I

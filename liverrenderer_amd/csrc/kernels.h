@@ -709,9 +709,10 @@ DEV void retire_and_compact_wave(SceneRef sc, RpRef rp, bool had_path, bool aliv
     finish_paths_wave(sc, rp, film, sample_out, sample_base, had_path && !alive, s.lane, s.res, (s.flags & PF_VALID) != 0);
 }
 
-// 4 waves per SIMD for every variant (128 VGPRs): one 1024-thread workgroup per CU, or four 256-thread ones
+// 4 waves per SIMD (128 VGPRs): one 1024-thread workgroup per CU, or four 256-thread ones.  BLOCK = 512 (one workgroup per CU, 2 waves per
+// SIMD, 256 VGPRs): the wide-record integrators (volpathmis: 18 weights per path), which at 128 registers spill 430 B per lane
 template <int INTEGRATOR, int BLOCK, bool LDS_BVH, bool LD>
-__global__ void __launch_bounds__(BLOCK, 4)
+__global__ void __launch_bounds__(BLOCK, BLOCK == 512 ? 2 : (BLOCK == 768 ? 3 : 4))
 k_render(ScenePtr scp, LaunchPtr lp) {
     SceneRef sc = *scp;
     const LRT_CONST DLaunch &A = *lp;                          // launch arguments: scalar loads where they are used
