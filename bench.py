@@ -81,6 +81,7 @@ def parse():
     p.add_argument("--scene", default=None, help="override the config's scene file")
     p.add_argument("--integrator", default=None, help="override the config's integrator")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--main-only", action="store_true", help="only the timed steps of the named configuration: no host_visible / hg_phase / cpu_baseline legs (profiling: every dispatch of the render kernel then belongs to the workload)")
     p.add_argument("--backend", default="nccl", help="process-group backend; gloo allows a multi-rank rehearsal on a single GPU")
     p.add_argument("--cpu-spp", type=int, default=0, help="spp of the bounded CPU-baseline sample (0: calibrate to ~15 s)")
     return p.parse_args()
@@ -274,7 +275,7 @@ def main():
         out["vs_baseline"] = round(value / cfg["published_msamples"], 2)
         out["config"]["published"] = {"value": cfg["published_msamples"], "unit": "Msamples/s", "source": "scenes/Liver-MultiMesh/mitsuba3/time.txt (BASELINE.md), GPU unstated"}
 
-    if rank == 0 and world == 1 and not backward:
+    if rank == 0 and world == 1 and not backward and not a.main_only:
         # SURVEY.md 8d's form of the metric: lrt_render entry to the developed image AND raw film in host memory (PCIe included).
         # Reported beside `value`, never as it: the bench contract takes `value` with everything resident in HBM.
         scene.render(spp=spp, seed=77, return_raw=True)
@@ -284,7 +285,7 @@ def main():
         out["host_visible"] = {"value": round(n_samples / hdt / 1e6, 3), "unit": "Msamples/s", "ms_per_step": round(hdt * 1e3, 3),
                                "note": "lrt_render with host output buffers: developed image + raw film copied over PCIe inside the call (SURVEY.md 8d t_render); reported beside `value`, never as it"}
 
-    if rank == 0 and world == 1 and a.config == "c3" and not (a.scene or a.integrator):
+    if rank == 0 and world == 1 and a.config == "c3" and not (a.scene or a.integrator) and not a.main_only:
         # BASELINE.json config 3 is worded "homogeneous medium + HG phase"; the scene file says isotropic.  The driver's
         # default line carries both: `value` on the file as committed, `hg_phase` on the same workload with the phase function set to
         # HG, g = 0.7, through the parameter interface (mi.traverse) - same size, same timed region, same number of steps.
@@ -304,7 +305,7 @@ def main():
                            "roofline_frac": round(hb / (hk * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if hk > 0 else None,
                            "iterations_per_sample": hi / (n_samples * a.steps), "records_per_sample": hr / (n_samples * a.steps)}
 
-    if rank == 0 and world == 1 and not a.no_cpu_baseline and not backward:
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and not backward and not a.main_only:
         # ---- CPU baseline (reported, not a target): the oracle's scalar_rgb restatement - SamplingIntegrator::render's scalar branch,
         # 32x32 blocks in Morton order, one std::thread per granted core (oracle/orc_render.cpp orc_render_scalar; SURVEY.md 8d,
         # BASELINE.md section 3.5) - on a bounded sample of the same workload: same scene and resolution at a reduced spp.
