@@ -132,6 +132,10 @@ def _pytorch_context_first():
     if not torch.cuda.is_available():
         return "no device"
     if not torch.cuda.is_initialized():
+        # (a rank of a one-process-per-GPU launch that has not chosen its device yet: its own GPU, not device 0 for every rank)
+        lr = os.environ.get("LOCAL_RANK")
+        if lr is not None and lr.isdigit() and torch.cuda.device_count() > 0:
+            torch.cuda.set_device(int(lr) % torch.cuda.device_count())
         torch.zeros(1, device="cuda")
     if not torch.cuda.is_initialized():
         raise RuntimeError("PyTorch is importable but its HIP context could not be created before libliverrt.so was loaded; "
