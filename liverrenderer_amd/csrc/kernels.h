@@ -15,6 +15,14 @@
 
 namespace lrt {
 
+// Developer aid (make dev DEVFLAGS=-DLRT_STAMP): section timers of the proven-free medium tiles (shader-clock cycles summed over the
+// waves' first lanes into DCounters::prof_wg is not used; the sums go to LDS and are printed by thread 0 at the end of the kernel).
+struct StampClock {
+    unsigned long long *acc; unsigned long long t; bool on;
+    DEV void start(unsigned long long *a, bool enable) { acc = a; on = enable; t = on ? __builtin_amdgcn_s_memtime() : 0ull; }
+    DEV void at(int k) { if (on) { const unsigned long long now = __builtin_amdgcn_s_memtime(); if ((threadIdx.x & 63u) == 0) atomicAdd(&acc[k], now - t); t = now; } }
+};
+
 struct PathState {
     V3 o, d, tp, res, lp; float maxt, eta, last_pdf; uint32_t flags, lane; uint64_t rng_state;
     float tdepth, si_t;        // biovolpath / biovolpath06: `tissueDepth`, distance returned by the previous trip's ray query
@@ -348,7 +356,7 @@ DEV V3 volpath_sample_emitter(SceneRef sc, SMP &rng, V3 ref_p, V3 ref_n, bool re
 // that is known to run its next trip, with the throughput already divided by the survival probability, the free-flight distance
 // in the record (ff_t) and, when the distance field proves that distance free of surfaces, PF_NOHIT.
 template <bool HET, typename SMP, typename TR>
-DEV bool volpath_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, const TR &tr, uint32_t &n_shadow, uint32_t &n_extra, bool fresh = false) {
+DEV bool volpath_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, const TR &tr, uint32_t &n_shadow, uint32_t &n_extra, bool fresh = false, StampClock *clk = nullptr) {
     constexpr bool PRE = !HET;
     uint32_t depth = s.flags & PF_DEPTH_MASK;
     bool proven_empty = (s.flags & PF_NOHIT) != 0;
@@ -384,7 +392,7 @@ DEV bool volpath_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, const 
         if (medium < 0) return;
         const DMedium M = tab(sc.media, medium);
         cache_t = medium_sampled_t(M, rng.next(), channel);
-        if (sc.grid.enabled) { const MI m2 = medium_interaction_at(M, ray, cache_t); if (m2.valid() && segment_proven_empty(sc.grid, ray.o, ray.d, m2.t)) nohit = PF_NOHIT; }
+        if (sc.grid.enabled) { const MI m2 = medium_interaction_at(M, ray, cache_t); if (m2.valid() && segment_free_of_surfaces(sc.grid, ray.o, ray.d, m2.t)) nohit = PF_NOHIT; }
     };
     bool active = true;
     if (!PRE) active = termination_stage();
@@ -429,6 +437,7 @@ DEV bool volpath_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, const 
     active = active && depth < max_depth;
     act_medium_scatter = act_medium_scatter && active;
     if (HET && act_null_scatter) { ray.o = mei.p; hkeep.t = si.t - mei.t; }    // :254-257 (si.t -= mei.t)
+    if (clk) clk->at(2);                                                // (developer section timer: record arrival + medium interaction)
     if (!act_medium_scatter) rng.skip(3);                               // volpath.cpp:407 (NEE), 288, 289
     if (act_medium_scatter) {
         const DMedium M = tab(sc.media, medium);
@@ -544,8 +553,10 @@ DEV bool volpath_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, const 
     // in n_extra; inside a medium the next free-flight distance is then known and the distance field may prove that the segment
     // reaches no surface: such paths are queued apart and skip their ray query.
     // !PRE (heterogeneous media): the same as a look-ahead on a copy of the generator; only the retirement and the proof are kept.
+    if (clk) clk->at(3);                                                // (scatter: weights, NEE rejection, phase sample)
     if (PRE) {
         if (active) { if (!termination_stage()) { active = false; n_extra += 1; } else free_flight_stage(); }
+        if (clk) clk->at(4);                                            // (termination + free-flight stage: draws, log, distance field)
     } else if (active) {
         SMP pk = rng;
         bool a2 = any_nonzero(throughput);
@@ -558,7 +569,7 @@ DEV bool volpath_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, const 
             if (!(HET && M.het)) {                    // a heterogeneous medium does not shorten the ray: its query is always the full one
                 const float t2 = medium_sampled_t(M, pk.next(), channel);
                 const MI m2 = medium_interaction_at(M, ray, t2);
-                if (m2.valid() && segment_proven_empty(sc.grid, ray.o, ray.d, m2.t)) nohit = PF_NOHIT;
+                if (m2.valid() && segment_free_of_surfaces(sc.grid, ray.o, ray.d, m2.t)) nohit = PF_NOHIT;
             }
         }
     }
@@ -722,6 +733,10 @@ k_render(ScenePtr scp, LaunchPtr lp) {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ uint32_t s_in[3], s_out[3], s_ticket, s_fresh;
     __shared__ unsigned long long s_fresh_base, s_prof[8];
+#ifdef LRT_STAMP
+    __shared__ unsigned long long s_stamp[8];
+    if (threadIdx.x < 8) s_stamp[threadIdx.x] = 0;
+#endif
     const uint32_t tid = threadIdx.x, lane_in_wave = tid & 63u;
     constexpr int MODE = (INTEGRATOR == LRT_INTEGRATOR_BIOVOLPATH || INTEGRATOR == LRT_INTEGRATOR_BIOVOLPATH06) ? 1 : (INTEGRATOR == LRT_INTEGRATOR_VOLPATH_HET ? 2 : ((INTEGRATOR == LRT_INTEGRATOR_VOLPATHMIS || INTEGRATOR == LRT_INTEGRATOR_VOLPATHMIS_PLAIN) ? 3 : 0));
     if (tid < 8) s_prof[tid] = 0;
@@ -766,6 +781,9 @@ k_render(ScenePtr scp, LaunchPtr lp) {
             t = (uint32_t) __builtin_amdgcn_readfirstlane((int) t);
             if (t >= n_tiles) break;
             const unsigned long long t_begin = (rp.profile & 1u) ? wall_clock64() : 0ull;
+#ifdef LRT_STAMP
+            StampClock clk; clk.start(s_stamp, t < ta);
+#endif
             bool had_path = false, alive = false;
             PathState s; s.flags = 0; s.lane = 0; s.res = V3(0.f);
             if (t < ta + tc + tb) {
@@ -779,19 +797,36 @@ k_render(ScenePtr scp, LaunchPtr lp) {
                 had_path = i < fresh;
                 if (had_path) s = generate_camera_path<LD>(sc, rp, A.pixel_list, A.lane_begin + fresh_base + i);
             }
+#ifdef LRT_STAMP
+            clk.at(0);                                                  // ticket, index arithmetic, load issue
+#endif
             if (had_path) {
                 SamplerT<LD> rng = lane_rng_resume<LD>(rp, s.lane, s.rng_state);
+#ifdef LRT_STAMP
+                clk.at(1);                                              // sampler resume (TEA) - needs the lane id: first wait for the record
+#endif
                 if (INTEGRATOR == LRT_INTEGRATOR_PATH) alive = LDS_BVH ? path_iteration(sc, rp, s, rng, tr_lds, n_shadow) : path_iteration(sc, rp, s, rng, tr_glb, n_shadow);
                 else if (INTEGRATOR == LRT_INTEGRATOR_BIOVOLPATH) { const bool fresh_tile = t >= ta + tc + tb; alive = LDS_BVH ? biovolpath_iteration(sc, rp, s, rng, tr_lds, n_shadow, n_extra, fresh_tile) : biovolpath_iteration(sc, rp, s, rng, tr_glb, n_shadow, n_extra, fresh_tile); }
                 else if (INTEGRATOR == LRT_INTEGRATOR_BIOVOLPATH06) alive = LDS_BVH ? biovolpath06_iteration(sc, rp, s, rng, tr_lds) : biovolpath06_iteration(sc, rp, s, rng, tr_glb);
                 else if (INTEGRATOR == LRT_INTEGRATOR_VOLPATHMIS) alive = LDS_BVH ? volpathmis_iteration<true>(sc, rp, s, rng, tr_lds, n_shadow) : volpathmis_iteration<true>(sc, rp, s, rng, tr_glb, n_shadow);
                 else if (INTEGRATOR == LRT_INTEGRATOR_VOLPATHMIS_PLAIN) alive = LDS_BVH ? volpathmis_iteration<false>(sc, rp, s, rng, tr_lds, n_shadow) : volpathmis_iteration<false>(sc, rp, s, rng, tr_glb, n_shadow);
                 else if (INTEGRATOR == LRT_INTEGRATOR_VOLPATH_HET) alive = LDS_BVH ? volpath_iteration<true>(sc, rp, s, rng, tr_lds, n_shadow, n_extra) : volpath_iteration<true>(sc, rp, s, rng, tr_glb, n_shadow, n_extra);
-                else { const bool fresh_tile = t >= ta + tc + tb; alive = LDS_BVH ? volpath_iteration<false>(sc, rp, s, rng, tr_lds, n_shadow, n_extra, fresh_tile) : volpath_iteration<false>(sc, rp, s, rng, tr_glb, n_shadow, n_extra, fresh_tile); }
+                else {
+                    const bool fresh_tile = t >= ta + tc + tb;
+#ifdef LRT_STAMP
+                    alive = LDS_BVH ? volpath_iteration<false>(sc, rp, s, rng, tr_lds, n_shadow, n_extra, fresh_tile, &clk) : volpath_iteration<false>(sc, rp, s, rng, tr_glb, n_shadow, n_extra, fresh_tile, &clk);
+#else
+                    alive = LDS_BVH ? volpath_iteration<false>(sc, rp, s, rng, tr_lds, n_shadow, n_extra, fresh_tile) : volpath_iteration<false>(sc, rp, s, rng, tr_glb, n_shadow, n_extra, fresh_tile);
+#endif
+                }
                 s.rng_state = rng.state;
                 n_trips += 1;
             }
             retire_and_compact_wave<MODE>(sc, rp, had_path, alive, s, A.film, A.sample_out, A.sample_base, parity ? A.q0 : A.q1, pool, P, s_out);
+#ifdef LRT_STAMP
+            clk.at(5);                                                  // compaction, stores, film sums
+            if (clk.on && lane_in_wave == 0) atomicAdd(&s_stamp[7], 1ull);
+#endif
             if ((rp.profile & 1u) && lane_in_wave == 0) {
                 const int region = t < ta ? 0 : (t < ta + tc ? 1 : (t < ta + tc + tb ? 2 : 3));
                 atomicAdd(&s_prof[region], wall_clock64() - t_begin); atomicAdd(&s_prof[4 + region], 1ull);
@@ -809,6 +844,11 @@ k_render(ScenePtr scp, LaunchPtr lp) {
         atomicAdd(&A.cnt->prof_wg[4], t_barrier);
     }
     if ((rp.profile & 1u) && tid < 8) { if (tid < 4) atomicAdd(&A.cnt->prof_cycles[tid], s_prof[tid]); else atomicAdd(&A.cnt->prof_tiles[tid - 4], s_prof[tid]); }
+#ifdef LRT_STAMP
+    __syncthreads();
+    if (tid == 0 && blockIdx.x == 7) printf("[stamp] proven-free tiles of workgroup 7: %llu; cycles per tile: ticket+load issue %.0f, record wait+TEA %.0f, medium interaction %.0f, scatter %.0f, termination+free flight %.0f, compact+store+film %.0f\n", s_stamp[7],
+        (double) s_stamp[0] / s_stamp[7], (double) s_stamp[1] / s_stamp[7], (double) s_stamp[2] / s_stamp[7], (double) s_stamp[3] / s_stamp[7], (double) s_stamp[4] / s_stamp[7], (double) s_stamp[5] / s_stamp[7]);
+#endif
     n_trips += n_extra;
     for (int off = 32; off > 0; off >>= 1) {
         n_shadow += __shfl_down(n_shadow, off); n_trips += __shfl_down(n_trips, off); n_loaded += __shfl_down(n_loaded, off);

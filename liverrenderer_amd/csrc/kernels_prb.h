@@ -295,7 +295,7 @@ DEV bool prb_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, const TR &
         if (a2) {
             const DMedium M = tab(sc.media, medium);
             MI m2 = medium_sample_interaction(M, ray, pk.next(), channel);
-            if (m2.valid() && segment_proven_empty(sc.grid, ray.o, ray.d, m2.t)) nohit = PF_NOHIT;
+            if (m2.valid() && segment_free_of_surfaces(sc.grid, ray.o, ray.d, m2.t)) nohit = PF_NOHIT;
         }
     }
     commit();
