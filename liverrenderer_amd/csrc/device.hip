@@ -879,27 +879,6 @@ void device_trace(DeviceScene *D, const lrt_rays_soa *rays, const lrt_hits_soa *
         float *t = mk(), *u = mk(), *v = mk(); uint32_t *prim = (uint32_t *) mk();
         uint32_t grid = (n + LRT_BLOCK - 1) / LRT_BLOCK;
         if (n) {
-#ifdef LRT_EXPERIMENT
-            if (D->use_lds && !any_hit && getenv("LRT_TRACE_REFILL") && !D->sc.root_is_leaf) {     // lane-refill experiment (kernels.h), timed
-                const int M = atoi(getenv("LRT_TRACE_REFILL"));
-                const uint32_t list_off = (D->lds.total_bytes + 15u) & ~15u, list_bytes = 16u * (uint32_t) std::max(M - 64, 1) * 28u;
-                if (list_off + list_bytes > 160u * 1024u - 512u) throw std::runtime_error("LRT_TRACE_REFILL: the ray lists do not fit the LDS next to this BVH image");
-                const uint32_t g = std::min<uint32_t>((uint32_t) D->n_cus, (n + 1023) / 1024);
-                hipEvent_t e0, e1; HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1));
-                for (int rep = 0; rep < 3; ++rep) {
-                    HIP_CHECK(hipEventRecord(e0, st));
-                    #define LRT_RF(MM) { HIP_CHECK(hipFuncSetAttribute((const void *) k_trace_lds_refill<MM>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512)); \
-                        k_trace_lds_refill<MM><<<g, 1024, list_off + list_bytes, st>>>((ScenePtr) D->d_sc, D->lds, list_off, ox, oy, oz, dx, dy, dz, tm, t, u, v, prim, n); }
-                    if (M == 64) LRT_RF(64) else if (M == 128) LRT_RF(128) else if (M == 192) LRT_RF(192) else if (M == 256) LRT_RF(256) else if (M == 0) { k_trace_lds<false><<<g, 1024, D->lds.total_bytes, st>>>((ScenePtr) D->d_sc, D->lds, ox, oy, oz, dx, dy, dz, tm, t, u, v, prim, n); }
-                    else throw std::runtime_error("LRT_TRACE_REFILL: 0 (plain), 64, 128, 192 or 256");
-                    #undef LRT_RF
-                    HIP_CHECK(hipEventRecord(e1, st)); HIP_CHECK(hipEventSynchronize(e1));
-                    float ms = 0.f; HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
-                    fprintf(stderr, "[lrt] trace refill M=%d: %u rays in %.3f ms (%.1f Mrays/s)\n", M, n, ms, n / ms * 1e-3);
-                }
-                (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
-            } else
-#endif
             if (D->use_lds) {                     // the render kernels' tracer: BVH image in LDS
                 const uint32_t g = std::min<uint32_t>((uint32_t) D->n_cus, (n + 1023) / 1024);
                 if (any_hit) k_trace_lds<true><<<g, 1024, D->lds.total_bytes, st>>>((ScenePtr) D->d_sc, D->lds, ox, oy, oz, dx, dy, dz, tm, t, u, v, prim, n);

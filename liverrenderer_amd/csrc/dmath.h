@@ -48,6 +48,27 @@ DEV float wave_sum(float v) {
     v = dpp_add<0x143, 0xc>(v);                                                                                           // row_bcast:31 into rows 2 and 3
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
+// Segmented inclusive sums over the wave (every lane active): lanes are grouped into runs of consecutive lanes (`head` marks the first lane
+// of a run); after the call lane i holds the sum of v over the lanes of its run up to and including i, for each of the N values at once.
+// Hillis-Steele steps with DPP row shifts (1, 2, 4, 8) and the two row broadcasts, each guarded by "a run began within the lanes skipped":
+// 2 VALU instructions per value and step, no LDS traffic, no loop over the runs.
+template <int N>
+DEV void wave_segmented_sums(float (&v)[N], bool head) {
+    uint32_t f = head ? 1u : 0u;
+#define LRT_SEG_STEP(CTRL, ROW_MASK) { \
+        const uint32_t pf = (uint32_t) __builtin_amdgcn_update_dpp(0, (int) f, CTRL, ROW_MASK, 0xf, true); \
+        _Pragma("unroll") for (int k = 0; k < N; ++k) { \
+            const float pv = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[k]), CTRL, ROW_MASK, 0xf, true)); \
+            v[k] = f ? v[k] : v[k] + pv; } \
+        f |= pf; }
+    LRT_SEG_STEP(0x111, 0xf) LRT_SEG_STEP(0x112, 0xf) LRT_SEG_STEP(0x114, 0xf) LRT_SEG_STEP(0x118, 0xf)      // row_shr:1, 2, 4, 8
+    LRT_SEG_STEP(0x142, 0xa) LRT_SEG_STEP(0x143, 0xc)                                                          // row_bcast:15 -> rows 1, 3; row_bcast:31 -> rows 2, 3
+#undef LRT_SEG_STEP
+}
+// the value of the previous / next lane of the wave (lane 0 / lane 63: `edge`): DPP wave shifts, every lane active
+DEV uint32_t wave_prev(uint32_t x, uint32_t edge) { return (uint32_t) __builtin_amdgcn_update_dpp((int) edge, (int) x, 0x138, 0xf, 0xf, false); }   // wave_shr:1
+DEV uint32_t wave_next(uint32_t x, uint32_t edge) { return (uint32_t) __builtin_amdgcn_update_dpp((int) edge, (int) x, 0x130, 0xf, 0xf, false); }   // wave_shl:1
+
 DEV float mulsign(float a, float s) { return u2f(f2u(a) ^ (f2u(s) & 0x80000000u)); }
 DEV float mulsign_neg(float a, float s) { return u2f(f2u(a) ^ (~f2u(s) & 0x80000000u)); }
 DEV float signf_(float x) { return u2f(0x3f800000u | (f2u(x) & 0x80000000u)); }

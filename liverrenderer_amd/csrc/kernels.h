@@ -15,7 +15,10 @@
 
 namespace lrt {
 
-// Developer aid (make dev DEVFLAGS=-DLRT_STAMP): section timers of the proven-free medium tiles (shader-clock cycles summed over the
+#ifndef LRT_STAMP_KIND
+#define LRT_STAMP_KIND 0        // which tile kind the section timers watch: 0 proven-free, 1 query, 2 surface, 3 fresh
+#endif
+// Developer aid (make dev DEVFLAGS=-DLRT_STAMP [-DLRT_STAMP_KIND=k]): section timers of one tile kind (shader-clock cycles summed over the
 // waves' first lanes into DCounters::prof_wg is not used; the sums go to LDS and are printed by thread 0 at the end of the kernel).
 struct StampClock {
     unsigned long long *acc; unsigned long long t; bool on;
@@ -253,6 +256,8 @@ DEV void finish_paths_wave(SceneRef sc, RpRef rp, float *__restrict__ film, floa
     if (rp.integrator == LRT_INTEGRATOR_PATH && !valid) L = V3(0.f);
     uint32_t pixel = 0xffffffffu;
     if (finishing) { int px, py; lane_to_pixel(sc, rp, lane, &px, &py); pixel = (uint32_t) (py - F.crop_offset_y) * (uint32_t) F.width + (uint32_t) (px - F.crop_offset_x); }
+    if (__ballot(finishing) == 0ull) return;
+#ifdef LRT_FILM_LEADER_LOOP
     unsigned long long todo = __ballot(finishing);
     const uint32_t me = threadIdx.x & 63u;
     while (todo) {
@@ -262,7 +267,6 @@ DEV void finish_paths_wave(SceneRef sc, RpRef rp, float *__restrict__ film, floa
         unsigned long long grp = __ballot(mine);
         float r = mine ? L.x : 0.f, g = mine ? L.y : 0.f, b = mine ? L.z : 0.f;
         r = wave_sum(r); g = wave_sum(g); b = wave_sum(b);
-        // the weight and alpha sums are counts of lanes (sums of ones: exact in binary32): population counts on the scalar unit
         const float w = (float) __popcll(grp), al = F.has_alpha ? (float) __popcll(__ballot(mine && valid)) : 0.f;
         if ((int) me == leader) {
             float *p = film + (size_t) key * F.channels;
@@ -271,6 +275,19 @@ DEV void finish_paths_wave(SceneRef sc, RpRef rp, float *__restrict__ film, floa
         }
         todo &= ~grp;
     }
+#else
+    // Queues keep lanes in lane order, so the finishing lanes of one pixel sit in RUNS of consecutive lanes: one segmented sum over the
+    // wave adds up every run at once (no loop over the pixels of the tile, no LDS round trip) and the last lane of each run issues the
+    // atomics.  A pixel that appears in two runs simply gets two sets of atomics.  Lanes that do not finish are runs of their own (zeros).
+    const uint32_t prev = wave_prev(pixel, 0xfffffffeu), next = wave_next(pixel, 0xfffffffeu);
+    float v[5] = { finishing ? L.x : 0.f, finishing ? L.y : 0.f, finishing ? L.z : 0.f, finishing ? 1.f : 0.f, (finishing && valid) ? 1.f : 0.f };
+    wave_segmented_sums(v, pixel != prev || !finishing);
+    if (finishing && pixel != next) {
+        float *p = film + (size_t) pixel * F.channels;
+        atomicAdd(p + 0, v[0]); atomicAdd(p + 1, v[1]); atomicAdd(p + 2, v[2]);
+        if (F.has_alpha) { atomicAdd(p + 3, v[4]); atomicAdd(p + 4, v[3]); } else atomicAdd(p + 3, v[3]);
+    }
+#endif
 }
 
 // ---------------------------------------------------------- volpath NEE
@@ -696,10 +713,11 @@ template <typename QS> DEV DPathStreams offset_streams(const QS &q, size_t off) 
     return r;
 }
 
-template <int MODE = 0>
+// READLANE: how the three regions' slot bases reach the lanes (see below)
+template <int MODE = 0, bool READLANE = true>
 DEV void retire_and_compact_wave(SceneRef sc, RpRef rp, bool had_path, bool alive, const PathState &s,
                                  float *__restrict__ film, float *__restrict__ sample_out, uint64_t sample_base,
-                                 const LRT_CONST DPathStreams &qout, size_t pool, uint32_t P, uint32_t *s_out /* LDS [3] */) {
+                                 const LRT_CONST DPathStreams &qout, size_t pool, uint32_t P, uint32_t *s_out /* LDS [3] */, StampClock *clk = nullptr) {
     const uint32_t lane_in_wave = threadIdx.x & 63u;
     // survivors first: their stores are the oldest memory operations the next tile's record loads have to wait for (the loads reuse
     // the registers the stores read), so they go out before the film sums, not after them
@@ -710,12 +728,21 @@ DEV void retire_and_compact_wave(SceneRef sc, RpRef rp, bool had_path, bool aliv
         const uint32_t c = (uint32_t) __popcll(lane_in_wave == 0 ? m0 : (lane_in_wave == 1 ? m1 : m2));
         if (c) base = atomicAdd(&s_out[lane_in_wave], c);
     }
-    const uint32_t b = __shfl(base, region);
+    // Lanes 0 .. 2 hold the three regions' slot bases.  READLANE: three v_readlane and two selects instead of one shuffle through LDS (ds_bpermute):
+    // in the volpath kernel the LDS is busy with the other waves' traversals and a round trip through it costs the wave hundreds of cycles
+    // (C3 -4.3 % time); the kernels that run at the VALU issue limit (path, biovolpath06: section 6a) lose 1 % to the extra instructions and keep the shuffle.
+    uint32_t b;
+    if (READLANE) {
+        const uint32_t b0 = (uint32_t) __builtin_amdgcn_readlane((int) base, 0), b1 = (uint32_t) __builtin_amdgcn_readlane((int) base, 1), b2 = (uint32_t) __builtin_amdgcn_readlane((int) base, 2);
+        b = region == 0 ? b0 : (region == 1 ? b1 : b2);
+    } else b = __shfl(base, region);
+    if (clk) clk->at(5);                                                // (developer section timer: ballots, slot counters)
     if (alive) {
         const unsigned long long mine = region == 0 ? m0 : (region == 1 ? m1 : m2);
         const uint32_t slot = b + (uint32_t) __popcll(mine & ((1ull << lane_in_wave) - 1ull));
         store_state<MODE>(qout, pool + (region == 0 ? slot : (region == 1 ? P + slot : 2u * P - 1u - slot)), s);
     }
+    if (clk) clk->at(6);                                                // (stores issued)
     if (rp.pass_out && had_path && !alive) rp.pass_out[lane_local_index(rp, s.lane)] = s.rng_state;       // next pass continues this stream
     finish_paths_wave(sc, rp, film, sample_out, sample_base, had_path && !alive, s.lane, s.res, (s.flags & PF_VALID) != 0);
 }
@@ -734,10 +761,11 @@ k_render(ScenePtr scp, LaunchPtr lp) {
     __shared__ uint32_t s_in[3], s_out[3], s_ticket, s_fresh;
     __shared__ unsigned long long s_fresh_base, s_prof[8];
 #ifdef LRT_STAMP
-    __shared__ unsigned long long s_stamp[8];
-    if (threadIdx.x < 8) s_stamp[threadIdx.x] = 0;
+    __shared__ unsigned long long s_stamp[16];
+    if (threadIdx.x < 16) s_stamp[threadIdx.x] = 0;
 #endif
     const uint32_t tid = threadIdx.x, lane_in_wave = tid & 63u;
+    constexpr bool READLANE = INTEGRATOR != LRT_INTEGRATOR_PATH && INTEGRATOR != LRT_INTEGRATOR_BIOVOLPATH06;
     constexpr int MODE = (INTEGRATOR == LRT_INTEGRATOR_BIOVOLPATH || INTEGRATOR == LRT_INTEGRATOR_BIOVOLPATH06) ? 1 : (INTEGRATOR == LRT_INTEGRATOR_VOLPATH_HET ? 2 : ((INTEGRATOR == LRT_INTEGRATOR_VOLPATHMIS || INTEGRATOR == LRT_INTEGRATOR_VOLPATHMIS_PLAIN) ? 3 : 0));
     if (tid < 8) s_prof[tid] = 0;
     const unsigned long long t_wg_start = (rp.profile & 1u) ? wall_clock64() : 0ull;
@@ -777,12 +805,12 @@ k_render(ScenePtr scp, LaunchPtr lp) {
         const uint32_t n_tiles = ta + tc + tb + tf;
         for (;;) {
             uint32_t t = 0;
-            if (lane_in_wave == 0) t = atomicAdd(&s_ticket, 1u);
+            if (lane_in_wave == 0) t = atomicAdd(&s_ticket, 1u);            // (tickets of 2 or 4 consecutive tiles, one LDS round trip each, and the next tile's ticket drawn before the compaction: measured, no better)
             t = (uint32_t) __builtin_amdgcn_readfirstlane((int) t);
             if (t >= n_tiles) break;
             const unsigned long long t_begin = (rp.profile & 1u) ? wall_clock64() : 0ull;
 #ifdef LRT_STAMP
-            StampClock clk; clk.start(s_stamp, t < ta);
+            StampClock clk; clk.start(s_stamp, LRT_STAMP_KIND == 0 ? t < ta : (LRT_STAMP_KIND == 1 ? (t >= ta && t < ta + tc) : (LRT_STAMP_KIND == 2 ? (t >= ta + tc && t < ta + tc + tb) : t >= ta + tc + tb)));
 #endif
             bool had_path = false, alive = false;
             PathState s; s.flags = 0; s.lane = 0; s.res = V3(0.f);
@@ -822,10 +850,12 @@ k_render(ScenePtr scp, LaunchPtr lp) {
                 s.rng_state = rng.state;
                 n_trips += 1;
             }
-            retire_and_compact_wave<MODE>(sc, rp, had_path, alive, s, A.film, A.sample_out, A.sample_base, parity ? A.q0 : A.q1, pool, P, s_out);
 #ifdef LRT_STAMP
-            clk.at(5);                                                  // compaction, stores, film sums
-            if (clk.on && lane_in_wave == 0) atomicAdd(&s_stamp[7], 1ull);
+            retire_and_compact_wave<MODE, READLANE>(sc, rp, had_path, alive, s, A.film, A.sample_out, A.sample_base, parity ? A.q0 : A.q1, pool, P, s_out, &clk);
+            clk.at(7);                                                  // film sums + atomics
+            if (clk.on && lane_in_wave == 0) atomicAdd(&s_stamp[15], 1ull);
+#else
+            retire_and_compact_wave<MODE, READLANE>(sc, rp, had_path, alive, s, A.film, A.sample_out, A.sample_base, parity ? A.q0 : A.q1, pool, P, s_out);
 #endif
             if ((rp.profile & 1u) && lane_in_wave == 0) {
                 const int region = t < ta ? 0 : (t < ta + tc ? 1 : (t < ta + tc + tb ? 2 : 3));
@@ -846,8 +876,8 @@ k_render(ScenePtr scp, LaunchPtr lp) {
     if ((rp.profile & 1u) && tid < 8) { if (tid < 4) atomicAdd(&A.cnt->prof_cycles[tid], s_prof[tid]); else atomicAdd(&A.cnt->prof_tiles[tid - 4], s_prof[tid]); }
 #ifdef LRT_STAMP
     __syncthreads();
-    if (tid == 0 && blockIdx.x == 7) printf("[stamp] proven-free tiles of workgroup 7: %llu; cycles per tile: ticket+load issue %.0f, record wait+TEA %.0f, medium interaction %.0f, scatter %.0f, termination+free flight %.0f, compact+store+film %.0f\n", s_stamp[7],
-        (double) s_stamp[0] / s_stamp[7], (double) s_stamp[1] / s_stamp[7], (double) s_stamp[2] / s_stamp[7], (double) s_stamp[3] / s_stamp[7], (double) s_stamp[4] / s_stamp[7], (double) s_stamp[5] / s_stamp[7]);
+    if (tid == 0 && blockIdx.x == 7) printf("[stamp] tiles of kind %d in workgroup 7: %llu; cycles per tile: ticket+load issue %.0f, record wait+TEA %.0f, to the end of the medium interaction / ray query %.0f, scatter + surface %.0f, termination+free flight %.0f, ballots+slots %.0f, stores %.0f, film %.0f\n", LRT_STAMP_KIND, s_stamp[15],
+        (double) s_stamp[0] / s_stamp[15], (double) s_stamp[1] / s_stamp[15], (double) s_stamp[2] / s_stamp[15], (double) s_stamp[3] / s_stamp[15], (double) s_stamp[4] / s_stamp[15], (double) s_stamp[5] / s_stamp[15], (double) s_stamp[6] / s_stamp[15], (double) s_stamp[7] / s_stamp[15]);
 #endif
     n_trips += n_extra;
     for (int off = 32; off > 0; off >>= 1) {
@@ -1029,91 +1059,5 @@ k_trace_lds(ScenePtr scp, DLdsInfo li, const float *ox, const float *oy, const f
     }
 }
 
-#ifdef LRT_EXPERIMENT
-// Developer experiment (`make exp`, LRT_TRACE_REFILL=M in device_trace): the closest-hit queries of k_trace_lds with lane refill inside the
-// traversal.  A wave owns M consecutive rays; rays 64.. wait in LDS, and a lane whose query is finished stores its hit and takes the next
-// waiting ray before the wave goes back to the node loop, so the idle tail comes once per M rays instead of once per 64.  Same arithmetic
-// as trace_lds (hits must be identical); measures what a two-sub-tile query tile of k_render could gain.
-template <int M>
-__global__ void __launch_bounds__(1024)
-k_trace_lds_refill(ScenePtr scp, DLdsInfo li, uint32_t list_off, const float *ox, const float *oy, const float *oz, const float *dx, const float *dy, const float *dz, const float *tmax,
-                   float *t, float *u, float *v, uint32_t *prim, uint32_t n) {
-    SceneRef sc = *scp;
-    extern __shared__ __align__(16) unsigned char smem[];
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    {
-        const uint4 *src = li.blob; uint4 *dst = reinterpret_cast<uint4 *>(smem);
-        for (uint32_t k = tid; k < li.blob_bytes / 16u; k += 1024) dst[k] = src[k];
-    }
-    LdsScene L;
-    L.nodes = reinterpret_cast<const float4 *>(smem + li.nodes_off); L.verts = reinterpret_cast<const float4 *>(smem + li.verts_off);
-    L.tris = reinterpret_cast<const uint2 *>(smem + li.tris_off);
-    L.n_faces = sc.n_faces;
-    __syncthreads();
-    constexpr int W = M > 64 ? M - 64 : 1;                                  // rays of a chunk that wait in LDS
-    volatile float *wl = reinterpret_cast<volatile float *>(smem + list_off) + (size_t) wave * W * 7;
-    uint16_t *stack = reinterpret_cast<uint16_t *>(smem + li.stack_off) + tid;
-    const uint32_t DONE = 0x10000u, IDLE = 0x20000u;
-    const uint32_t n_chunks = (n + M - 1) / M;
-    for (uint32_t chunk = blockIdx.x * 16u + wave; chunk < n_chunks; chunk += gridDim.x * 16u) {
-        const uint32_t base = chunk * M, cnt = min((uint32_t) M, n - base);
-        for (uint32_t k = lane; k + 64u < cnt; k += 64u) {
-            const uint32_t i = base + 64u + k;
-            wl[0 * W + k] = ox[i]; wl[1 * W + k] = oy[i]; wl[2 * W + k] = oz[i]; wl[3 * W + k] = dx[i]; wl[4 * W + k] = dy[i]; wl[5 * W + k] = dz[i]; wl[6 * W + k] = tmax[i];
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        uint32_t my = base + lane, next = 64u, cur = lane < cnt ? 0u : IDLE;
-        V3 o(0.f), d(0.f); float maxt = 0.f;
-        if (lane < cnt) { o = V3(ox[my], oy[my], oz[my]); d = V3(dx[my], dy[my], dz[my]); maxt = tmax[my]; }
-        Hit best; best.t = kInf; best.u = best.v = 0.f; best.prim = 0xffffffffu;
-        float ix = slab_rcp(d.x), iy = slab_rcp(d.y), iz = slab_rcp(d.z);
-        float oxx = -o.x * ix, oyy = -o.y * iy, ozz = -o.z * iz;
-        int sp = 0;
-        for (;;) {
-            while (cur < 0x8000u) {
-                const f32x2 vix = { ix, ix }, viy = { iy, iy }, viz = { iz, iz }, vox = { oxx, oxx }, voy = { oyy, oyy }, voz = { ozz, ozz };
-                const float4 *nd = L.nodes + 4 * cur;
-                float4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3];
-                float limit = fmin_(best.t, maxt);
-                const f32x2 vax = pk_fma(f32x2{ n0.x, n0.y }, vix, vox), vay = pk_fma(f32x2{ n0.z, n0.w }, viy, voy), vaz = pk_fma(f32x2{ n2.x, n2.y }, viz, voz);
-                const f32x2 vbx = pk_fma(f32x2{ n1.x, n1.y }, vix, vox), vby = pk_fma(f32x2{ n1.z, n1.w }, viy, voy), vbz = pk_fma(f32x2{ n2.z, n2.w }, viz, voz);
-                float tmin0 = fmax_(fmax_(fmin_(vax.x, vax.y), fmin_(vay.x, vay.y)), fmax_(fmin_(vaz.x, vaz.y), 0.f));
-                float tmax0 = fmin_(fmin_(fmax_(vax.x, vax.y), fmax_(vay.x, vay.y)), fmin_(fmax_(vaz.x, vaz.y), limit));
-                float tmin1 = fmax_(fmax_(fmin_(vbx.x, vbx.y), fmin_(vby.x, vby.y)), fmax_(fmin_(vbz.x, vbz.y), 0.f));
-                float tmax1 = fmin_(fmin_(fmax_(vbx.x, vbx.y), fmax_(vby.x, vby.y)), fmin_(fmax_(vbz.x, vbz.y), limit));
-                bool h0 = tmin0 <= tmax0 * 1.000002f + 1e-30f, h1 = tmin1 <= tmax1 * 1.000002f + 1e-30f;
-                const uint32_t c0 = f2u(n3.x), c1 = f2u(n3.y);
-                if (h0 && h1) { bool swap = tmin1 < tmin0; stack[sp * 1024] = (uint16_t) (swap ? c0 : c1); ++sp; cur = swap ? c1 : c0; }
-                else if (h0 || h1) cur = h0 ? c0 : c1;
-                else if (sp == 0) cur = DONE;
-                else { --sp; cur = stack[sp * 1024]; }
-            }
-            if (cur < DONE) {
-                uint32_t slot = cur & 0x7fffu, last;
-                do { const uint2 ixw = L.tris[slot]; last = (ixw.y >> 16) & 1u; test_tri_lds(L, ixw, slot, o, d, maxt, best); ++slot; } while (!last);
-                if (sp == 0) cur = DONE; else { --sp; cur = stack[sp * 1024]; }
-            }
-            const bool fin = cur == DONE;
-            const unsigned long long fm = __ballot(fin);
-            if (fm) {
-                if (fin) {
-                    t[my] = best.t; u[my] = best.u; v[my] = best.v; prim[my] = best.prim != 0xffffffffu ? (best.prim & 0x7fffu) : 0xffffffffu;
-                    const uint32_t k = next + (uint32_t) __popcll(fm & ((1ull << lane) - 1ull));
-                    if (M > 64 && k < cnt) {
-                        const uint32_t w = k - 64u;
-                        o = V3(wl[0 * W + w], wl[1 * W + w], wl[2 * W + w]); d = V3(wl[3 * W + w], wl[4 * W + w], wl[5 * W + w]); maxt = wl[6 * W + w];
-                        my = base + k; cur = 0u; sp = 0;
-                        best.t = kInf; best.u = best.v = 0.f; best.prim = 0xffffffffu;
-                        ix = slab_rcp(d.x); iy = slab_rcp(d.y); iz = slab_rcp(d.z); oxx = -o.x * ix; oyy = -o.y * iy; ozz = -o.z * iz;
-                    } else cur = IDLE;
-                }
-                next += (uint32_t) __popcll(fm);
-            }
-            if (__ballot(cur != IDLE) == 0ull) break;
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-}
-#endif
 
 } // namespace lrt

@@ -450,7 +450,8 @@ k_render_prb(ScenePtr scp, LaunchPtr lp) {
             const unsigned long long m0 = __ballot(alive && region == 0), m1 = __ballot(alive && region == 1), m2 = __ballot(alive && region == 2);
             uint32_t base = 0;
             if (lane_in_wave < 3) { const uint32_t c = (uint32_t) __popcll(lane_in_wave == 0 ? m0 : (lane_in_wave == 1 ? m1 : m2)); if (c) base = atomicAdd(&s_out[lane_in_wave], c); }
-            const uint32_t b = __shfl(base, region);
+            const uint32_t b0 = (uint32_t) __builtin_amdgcn_readlane((int) base, 0), b1 = (uint32_t) __builtin_amdgcn_readlane((int) base, 1), b2 = (uint32_t) __builtin_amdgcn_readlane((int) base, 2);
+            const uint32_t b = region == 0 ? b0 : (region == 1 ? b1 : b2);          // (v_readlane, not a shuffle through LDS: see retire_and_compact_wave)
             if (alive) {
                 const uint32_t slot = b + (uint32_t) __popcll((region == 0 ? m0 : (region == 1 ? m1 : m2)) & ((1ull << lane_in_wave) - 1ull));
                 const uint32_t rec = region == 0 ? slot : (region == 1 ? P + slot : 2u * P - 1u - slot);

@@ -15,4 +15,9 @@ for (w, h, spp, seed) in ((128, 72, 16, 0), (96, 54, 64, 3)):
     same = (g.view(np.uint32) == c.view(np.uint32)).all(axis=1).mean()
     print(f"{os.environ.get('LRT_LIBRARY', 'in-tree')}: {w}x{h}x{spp}: lanes identical {same:.6f}, trips {st['n_iter']} (oracle {o.last_stats['n_iter']})")
     ok &= (same == 1.0) and st["n_iter"] == o.last_stats["n_iter"]
+    from test_parity_gpu import film_close
+    raw = sc.render(return_raw=True, seed=seed)[1]; ora = o.render(return_raw=True, seed=seed)[1]
+    fc = film_close(raw, ora).all(); wexact = np.array_equal(raw[..., -1], ora[..., -1])
+    print(f"   film close to the oracle's: {fc}; weight channel identical: {wexact}")
+    ok &= bool(fc) and bool(wexact)
 sys.exit(0 if ok else 1)
