@@ -85,7 +85,7 @@ DEV Hit trace(SceneRef sc, const Ray &r, int *__restrict__ stack /* &lds[threadI
             float tmax0 = fmin_(fmin_(fmax_(ax0, ax1), fmax_(ay0, ay1)), fmin_(fmax_(az0, az1), limit));
             float tmin1 = fmax_(fmax_(fmin_(bx0, bx1), fmin_(by0, by1)), fmax_(fmin_(bz0, bz1), 0.f));
             float tmax1 = fmin_(fmin_(fmax_(bx0, bx1), fmax_(by0, by1)), fmin_(fmax_(bz0, bz1), limit));
-            bool h0 = tmin0 <= tmax0 * 1.000002f + 1e-30f, h1 = tmin1 <= tmax1 * 1.000002f + 1e-30f;
+            bool h0 = tmin0 <= tmax0 * 1.000002f, h1 = tmin1 <= tmax1 * 1.000002f;      // (tmin >= 0, so an additive floor on the right-hand side decides nothing)
             int r0 = (int) f2u(n3.x), r1 = (int) f2u(n3.y);
             uint32_t c0 = r0 < 0 ? (0x80000000u | (uint32_t) ~r0) : (uint32_t) r0;
             uint32_t c1 = r1 < 0 ? (0x80000000u | (uint32_t) ~r1) : (uint32_t) r1;
@@ -93,7 +93,7 @@ DEV Hit trace(SceneRef sc, const Ray &r, int *__restrict__ stack /* &lds[threadI
                 bool swap = tmin1 < tmin0;
                 stack[sp * LRT_BLOCK] = (int) (swap ? c0 : c1); ++sp;
                 cur = swap ? c1 : c0;
-            } else if (h0 || h1) cur = h0 ? c0 : c1;
+            } else if (h0 || h1) cur = h0 ? c0 : c1;                    // (two flat predicated regions instead of these nested three: measured, +0.4 % time)
             else if (sp == 0) cur = DONE;
             else { --sp; cur = (uint32_t) stack[sp * LRT_BLOCK]; }
         }
@@ -145,6 +145,12 @@ DEV void test_tri_lds(const LdsScene &L, uint2 ix, uint32_t slot, V3 o, V3 d, fl
     if (t < best.t || f < (best.prim & 0x7fffu)) { best.t = t; best.u = u; best.v = v; best.prim = f | (slot << 16); }
 }
 
+#ifdef LRT_TRAV_STATS
+__device__ unsigned long long g_trav[8];            // developer counters: [ANY ? 4 : 0] + { node-loop wave iterations, active lanes in them, leaf-loop wave iterations, active lanes }
+#define LRT_TRAV_COUNT(k) { const unsigned long long m_ = __ballot(true); if ((threadIdx.x & 63u) == (uint32_t) (__ffsll((long long) m_) - 1)) { atomicAdd(&g_trav[(ANY_HIT ? 4 : 0) + k], 1ull); atomicAdd(&g_trav[(ANY_HIT ? 4 : 0) + k + 1], (unsigned long long) __popcll(m_)); } }
+#else
+#define LRT_TRAV_COUNT(k)
+#endif
 template <bool ANY_HIT, int STRIDE>
 DEV Hit trace_lds(const LdsScene &L, const Ray &r, uint16_t *__restrict__ stack /* &lds_stack[threadIdx.x] */) {
     Hit best; best.t = kInf; best.u = best.v = 0.f; best.prim = 0xffffffffu;
@@ -170,6 +176,7 @@ DEV Hit trace_lds(const LdsScene &L, const Ray &r, uint16_t *__restrict__ stack 
     int sp = 0; uint32_t cur = 0;
     for (;;) {
         while (cur < 0x8000u) {
+            LRT_TRAV_COUNT(0)
             const float4 *nd = L.nodes + 4 * cur;
             float4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3];
             float limit = fmin_(best.t, r.maxt);
@@ -182,7 +189,7 @@ DEV Hit trace_lds(const LdsScene &L, const Ray &r, uint16_t *__restrict__ stack 
             float tmax0 = fmin_(fmin_(fmax_(ax0, ax1), fmax_(ay0, ay1)), fmin_(fmax_(az0, az1), limit));
             float tmin1 = fmax_(fmax_(fmin_(bx0, bx1), fmin_(by0, by1)), fmax_(fmin_(bz0, bz1), 0.f));
             float tmax1 = fmin_(fmin_(fmax_(bx0, bx1), fmax_(by0, by1)), fmin_(fmax_(bz0, bz1), limit));
-            bool h0 = tmin0 <= tmax0 * 1.000002f + 1e-30f, h1 = tmin1 <= tmax1 * 1.000002f + 1e-30f;
+            bool h0 = tmin0 <= tmax0 * 1.000002f, h1 = tmin1 <= tmax1 * 1.000002f;      // (tmin >= 0, so an additive floor on the right-hand side decides nothing)
             const uint32_t c0 = f2u(n3.x), c1 = f2u(n3.y);             // already work items (device.hip builds the LDS image)
             if (h0 && h1) {
                 bool swap = tmin1 < tmin0;
@@ -195,6 +202,7 @@ DEV Hit trace_lds(const LdsScene &L, const Ray &r, uint16_t *__restrict__ stack 
         if (cur == DONE) break;
         uint32_t slot = cur & 0x7fffu, last;
         do {
+            LRT_TRAV_COUNT(2)
             const uint2 ix = L.tris[slot];
             last = (ix.y >> 16) & 1u;
             test_tri_lds(L, ix, slot, o, d, r.maxt, best);

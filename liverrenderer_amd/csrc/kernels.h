@@ -874,6 +874,9 @@ k_render(ScenePtr scp, LaunchPtr lp) {
         atomicAdd(&A.cnt->prof_wg[4], t_barrier);
     }
     if ((rp.profile & 1u) && tid < 8) { if (tid < 4) atomicAdd(&A.cnt->prof_cycles[tid], s_prof[tid]); else atomicAdd(&A.cnt->prof_tiles[tid - 4], s_prof[tid]); }
+#ifdef LRT_TRAV_STATS
+    if (tid == 0 && blockIdx.x == 0) printf("[trav, so far] closest: node steps %llu (lanes %.1f), leaf steps %llu (lanes %.1f); any-hit: node steps %llu (lanes %.1f), leaf steps %llu (lanes %.1f)\n", g_trav[0], (double) g_trav[1] / g_trav[0], g_trav[2], (double) g_trav[3] / g_trav[2], g_trav[4], (double) g_trav[5] / g_trav[4], g_trav[6], (double) g_trav[7] / g_trav[6]);
+#endif
 #ifdef LRT_STAMP
     __syncthreads();
     if (tid == 0 && blockIdx.x == 7) printf("[stamp] tiles of kind %d in workgroup 7: %llu; cycles per tile: ticket+load issue %.0f, record wait+TEA %.0f, to the end of the medium interaction / ray query %.0f, scatter + surface %.0f, termination+free flight %.0f, ballots+slots %.0f, stores %.0f, film %.0f\n", LRT_STAMP_KIND, s_stamp[15],
