@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("LRT_LIBRARY") or os.path.join(_HERE, "libliverrt.so")
 OK = 0
 INTEGRATOR = {"path": 0, "volpath": 1, "prbvolpath": 2, "biovolpath": 3, "biovolpath06": 4, "volpathmis": 5}
 MEDIUM = {"homogeneous": 0, "liver": 1, "parenchyma": 2, "glissonCapsule": 3, "heterogeneous": 4}
+EMITTER = {"area": 0, "envmap": 1, "constant": 2}
 
 
 class ShapeDesc(C.Structure):

@@ -320,12 +320,16 @@ DeviceScene *device_scene_create(const lrt_scene_desc &d, int device) {
 #ifndef LRT_DEV_BLOCK
 #define LRT_DEV_BLOCK 1024
 #endif
-            LRT_SMEM((k_render<LRT_DEV_INTEGRATOR, LRT_DEV_BLOCK, true, LRT_DEV_LD>)); LRT_SMEM((k_trace_lds<true>)); LRT_SMEM((k_trace_lds<false>));
+            LRT_SMEM((k_render<LRT_DEV_INTEGRATOR, LRT_DEV_BLOCK, true, LRT_DEV_LD>)); LRT_SMEM((k_render<LRT_DEV_INTEGRATOR, LRT_DEV_BLOCK, true, LRT_DEV_LD, true>)); LRT_SMEM((k_trace_lds<true>)); LRT_SMEM((k_trace_lds<false>));
 #else
             LRT_SMEM((k_render<LRT_INTEGRATOR_PATH, 1024, true, false>)); LRT_SMEM((k_render<LRT_INTEGRATOR_VOLPATH, 1024, true, false>));
             LRT_SMEM((k_render<LRT_INTEGRATOR_PATH, 1024, true, true>)); LRT_SMEM((k_render<LRT_INTEGRATOR_VOLPATH, 1024, true, true>));
             LRT_SMEM((k_render<LRT_INTEGRATOR_BIOVOLPATH, 1024, true, false>)); LRT_SMEM((k_render<LRT_INTEGRATOR_BIOVOLPATH, 1024, true, true>));
             LRT_SMEM((k_render<LRT_INTEGRATOR_BIOVOLPATH06, 1024, true, false>)); LRT_SMEM((k_render<LRT_INTEGRATOR_BIOVOLPATH06, 1024, true, true>));
+            LRT_SMEM((k_render<LRT_INTEGRATOR_PATH, 1024, true, false, true>)); LRT_SMEM((k_render<LRT_INTEGRATOR_VOLPATH, 1024, true, false, true>));       // (compact records)
+            LRT_SMEM((k_render<LRT_INTEGRATOR_PATH, 1024, true, true, true>)); LRT_SMEM((k_render<LRT_INTEGRATOR_VOLPATH, 1024, true, true, true>));
+            LRT_SMEM((k_render<LRT_INTEGRATOR_BIOVOLPATH, 1024, true, false, true>)); LRT_SMEM((k_render<LRT_INTEGRATOR_BIOVOLPATH, 1024, true, true, true>));
+            LRT_SMEM((k_render<LRT_INTEGRATOR_BIOVOLPATH06, 1024, true, false, true>)); LRT_SMEM((k_render<LRT_INTEGRATOR_BIOVOLPATH06, 1024, true, true, true>));
             // (the wide-record integrators run 768-thread workgroups: 3 waves per SIMD, 168 VGPRs instead of 128 + 200 - 430 B of scratch per lane;
             //  measured on the f4 bench configs: volpathmis +58 %, volpath with heterogeneous media +9 %; 512 threads: +54 % / -18 %)
             LRT_SMEM((k_render<LRT_INTEGRATOR_VOLPATH_HET, LRT_WIDE_BLOCK, true, false>)); LRT_SMEM((k_render<LRT_INTEGRATOR_VOLPATH_HET, LRT_WIDE_BLOCK, true, true>));
@@ -521,7 +525,7 @@ static void ensure_workspace(DeviceScene *D, uint32_t capacity) {
     for (DPathStreams *q : { &D->q[0], &D->q[1] }) {
         q->o_maxt = (float4 *) alloc((size_t) capacity * 16); q->d_eta = (float4 *) alloc((size_t) capacity * 16); q->tp_pdf = (float4 *) alloc((size_t) capacity * 16);
         q->res_flags = (float4 *) alloc((size_t) capacity * 16); q->lp_lane = (float4 *) alloc((size_t) capacity * 16);
-        q->rng = (uint2 *) alloc((size_t) capacity * 8); q->tdepth = (float2 *) alloc((size_t) capacity * 8);
+        q->rng = (uint2 *) alloc((size_t) capacity * 16); q->tdepth = (float2 *) alloc((size_t) capacity * 8);     // rng: 16 B per entry (compact records keep state | lane | sampler word there)
         if (D->has_het || want_mis) q->hit = (float4 *) alloc((size_t) capacity * 16);
         if (want_mis) for (float4 **w : { &q->w1, &q->w2, &q->w3, &q->w4 }) *w = (float4 *) alloc((size_t) capacity * 16);
     }
@@ -744,22 +748,36 @@ static void run_wavefront(DeviceScene *D, const lrt_scene_desc &d, const Resolve
     else {
         DLaunch a{}; a.rp = rp; a.li = D->lds; a.q0 = D->q[0]; a.q1 = D->q[1]; a.P = g.P; a.cnt = D->counters; a.pixel_list = pixel_list;
         a.lane_begin = lane_begin; a.n = n_lanes; a.film = film; a.sample_out = sample_out; a.sample_base = lane_begin;
+        // Compact records (kernels.h, store_state): only an area emitter's pdf reads the last scatter position, so a scene without one does not queue it.
+        // Instances exist for the 1024-thread LDS kernels of path / volpath (homogeneous media) / biovolpath / biovolpath06.  LRT_WIDE_RECORDS: developer switch.
+        bool compact = D->use_lds && !getenv("LRT_WIDE_RECORDS") && O.integrator != LRT_INTEGRATOR_VOLPATHMIS && !(O.integrator == LRT_INTEGRATOR_VOLPATH && D->has_het);
+        for (uint32_t i = 0; i < d.n_emitters; ++i) if (d.emitters[i].type == LRT_EMITTER_AREA) compact = false;
+        a.rp.compact = compact ? 1u : 0u;
         const LaunchPtr lp = push_launch(D, a);
 #ifdef LRT_DEV_VOLPATH_ONLY
         if (!(D->use_lds && (O.integrator == LRT_DEV_INTEGRATOR || (LRT_DEV_INTEGRATOR == LRT_INTEGRATOR_VOLPATH_HET && D->has_het)) && (rp.ld_count != 0) == LRT_DEV_LD)) throw std::runtime_error("developer build: one integrator / sampler / LDS BVH only");
-        k_render<LRT_DEV_INTEGRATOR, LRT_DEV_BLOCK, true, LRT_DEV_LD><<<g.n_wg, LRT_DEV_BLOCK, g.smem, st>>>((ScenePtr) D->d_sc, lp);
+        if (compact) k_render<LRT_DEV_INTEGRATOR, LRT_DEV_BLOCK, true, LRT_DEV_LD, true><<<g.n_wg, LRT_DEV_BLOCK, g.smem, st>>>((ScenePtr) D->d_sc, lp);
+        else k_render<LRT_DEV_INTEGRATOR, LRT_DEV_BLOCK, true, LRT_DEV_LD><<<g.n_wg, LRT_DEV_BLOCK, g.smem, st>>>((ScenePtr) D->d_sc, lp);
         #define LRT_LAUNCH_I(BS, LDSB)
         #define LRT_LAUNCH(I, BS, LDSB)
 #else
         #define LRT_LAUNCH(I, BS, LDSB) do { if (rp.ld_count) k_render<I, BS, LDSB, true><<<g.n_wg, BS, g.smem, st>>>((ScenePtr) D->d_sc, lp); \
                                              else k_render<I, BS, LDSB, false><<<g.n_wg, BS, g.smem, st>>>((ScenePtr) D->d_sc, lp); } while (0)
+        #define LRT_LAUNCH_COMPACT(I) do { if (rp.ld_count) k_render<I, 1024, true, true, true><<<g.n_wg, 1024, g.smem, st>>>((ScenePtr) D->d_sc, lp); \
+                                           else k_render<I, 1024, true, false, true><<<g.n_wg, 1024, g.smem, st>>>((ScenePtr) D->d_sc, lp); } while (0)
         #define LRT_LAUNCH_I(BS, LDSB) do { switch (O.integrator) { \
             case LRT_INTEGRATOR_PATH: LRT_LAUNCH(LRT_INTEGRATOR_PATH, BS, LDSB); break; \
             case LRT_INTEGRATOR_BIOVOLPATH: LRT_LAUNCH(LRT_INTEGRATOR_BIOVOLPATH, BS, LDSB); break; \
             case LRT_INTEGRATOR_BIOVOLPATH06: LRT_LAUNCH(LRT_INTEGRATOR_BIOVOLPATH06, BS, LDSB); break; \
             case LRT_INTEGRATOR_VOLPATHMIS: if (d.use_spectral_mis) LRT_LAUNCH(LRT_INTEGRATOR_VOLPATHMIS, (LDSB ? LRT_WIDE_BLOCK : BS), LDSB); else LRT_LAUNCH(LRT_INTEGRATOR_VOLPATHMIS_PLAIN, (LDSB ? LRT_WIDE_BLOCK : BS), LDSB); break; \
             default: if (D->has_het) LRT_LAUNCH(LRT_INTEGRATOR_VOLPATH_HET, (LDSB ? LRT_WIDE_BLOCK : BS), LDSB); else LRT_LAUNCH(LRT_INTEGRATOR_VOLPATH, BS, LDSB); } } while (0)
-        if (D->use_lds) LRT_LAUNCH_I(1024, true); else LRT_LAUNCH_I(LRT_BLOCK, false);
+        if (compact) switch (O.integrator) {
+            case LRT_INTEGRATOR_PATH: LRT_LAUNCH_COMPACT(LRT_INTEGRATOR_PATH); break;
+            case LRT_INTEGRATOR_BIOVOLPATH: LRT_LAUNCH_COMPACT(LRT_INTEGRATOR_BIOVOLPATH); break;
+            case LRT_INTEGRATOR_BIOVOLPATH06: LRT_LAUNCH_COMPACT(LRT_INTEGRATOR_BIOVOLPATH06); break;
+            default: LRT_LAUNCH_COMPACT(LRT_INTEGRATOR_VOLPATH); }
+        else if (D->use_lds) LRT_LAUNCH_I(1024, true); else LRT_LAUNCH_I(LRT_BLOCK, false);
+        #undef LRT_LAUNCH_COMPACT
 #endif
         #undef LRT_LAUNCH_I
         #undef LRT_LAUNCH

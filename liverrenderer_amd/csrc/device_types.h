@@ -146,6 +146,7 @@ struct DRenderParams {
     uint32_t tile_rank, tile_count;
     int32_t grad_medium;       // PRB adjoint: medium whose parameters are differentiated, -1: all media into one set
     uint32_t tiles_x, tiles_y, profile;   // profile: per-region tile timing into DCounters (developer aid, LRT_DEBUG_LAUNCH)
+    uint32_t compact;          // 80-byte records (scenes without area emitters: the last scatter position is never read): see store_state
     uint64_t n_lanes;          // lanes this launch renders
     const uint32_t *pixel_slot; // tile-sharded renders: pixel -> index in the rank's pixel list (rank-local lane index), else null
     // multi-pass renders (integrator.cpp:176-184,275-293,343-353): spp above is the samples of ONE pass

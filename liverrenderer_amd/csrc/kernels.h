@@ -28,6 +28,7 @@ struct StampClock {
 
 struct PathState {
     V3 o, d, tp, res, lp; float maxt, eta, last_pdf; uint32_t flags, lane; uint64_t rng_state;
+    uint32_t rng_word;         // compact records: the TEA word behind the lane's sampler stream (independent: v1, ld: v0), kept instead of recomputed every trip
     float tdepth, si_t;        // biovolpath / biovolpath06: `tissueDepth`, distance returned by the previous trip's ray query
     float ff_t;                // volpath (homogeneous media): the free-flight distance the look-ahead already drew for this trip (NaN: none); rides in the maxt slot
     float bio_dist; bool bio_hep;   // biovolpath: the element competition the look-ahead already ran for this trip (distance, NaN = none; hepatocytes won)
@@ -40,20 +41,23 @@ struct PathState {
 // MODE: 0 path / volpath (88 B), 1 biovolpath* (96 B), 2 volpath with heterogeneous media (104 B), 3 volpathmis (168 B)
 // A record as the stream loads return it.  Fetching (the loads) and unpacking (the first use of their results) are apart so that the
 // render kernel can ask for a tile's records while the previous tile is still being compacted and stored.
-struct RawState { float4 a, b, c, d, e; uint2 r; float2 td; float4 hit, w1, w2, w3, w4; };
+struct RawState { float4 a, b, c, d, e; uint2 r; uint4 r4; float2 td; float4 hit, w1, w2, w3, w4; };
 template <int MODE = 0, typename QS>
-DEV void fetch_state(const QS &q, size_t i, RawState &w) {
-    w.a = q.o_maxt[i]; w.b = q.d_eta[i]; w.c = q.tp_pdf[i]; w.d = q.res_flags[i]; w.e = q.lp_lane[i]; w.r = q.rng[i];
+DEV void fetch_state(const QS &q, size_t i, RawState &w, bool compact = false) {
+    w.a = q.o_maxt[i]; w.b = q.d_eta[i]; w.c = q.tp_pdf[i]; w.d = q.res_flags[i];
+    if (compact) w.r4 = reinterpret_cast<const uint4 *>(q.rng)[i];                       // state | lane | sampler word: no last-scatter-position stream
+    else { w.e = q.lp_lane[i]; w.r = q.rng[i]; }
     if (MODE == 1) w.td = q.tdepth[i];
     if (MODE == 2 || MODE == 3) w.hit = q.hit[i];
     if (MODE == 3) { w.w1 = q.w1[i]; w.w2 = q.w2[i]; w.w3 = q.w3[i]; w.w4 = q.w4[i]; }
 }
 template <int MODE = 0>
-DEV void unpack_state(const RawState &w, PathState &s) {
-    const float4 a = w.a, b = w.b, c = w.c, d = w.d, e = w.e; const uint2 r = w.r;
+DEV void unpack_state(const RawState &w, PathState &s, bool compact = false) {
+    const float4 a = w.a, b = w.b, c = w.c, d = w.d;
     s.o = V3(a.x, a.y, a.z); s.maxt = a.w; s.d = V3(b.x, b.y, b.z); s.eta = b.w;
     s.tp = V3(c.x, c.y, c.z); s.last_pdf = c.w; s.res = V3(d.x, d.y, d.z); s.flags = f2u(d.w);
-    s.lp = V3(e.x, e.y, e.z); s.lane = f2u(e.w); s.rng_state = ((uint64_t) r.y << 32) | r.x;
+    if (compact) { const uint4 r4 = w.r4; s.lp = V3(0.f); s.lane = r4.z; s.rng_word = r4.w; s.rng_state = ((uint64_t) r4.y << 32) | r4.x; }
+    else { const float4 e = w.e; const uint2 r = w.r; s.lp = V3(e.x, e.y, e.z); s.lane = f2u(e.w); s.rng_state = ((uint64_t) r.y << 32) | r.x; }
     if (MODE == 0) { s.ff_t = a.w; s.maxt = kLargest; }          // a queued ray always comes from spawn_ray: maxt = largest float
     if (MODE == 1) { s.si_t = a.w; s.maxt = kLargest; const float2 td = w.td; s.tdepth = __builtin_fabsf(td.x); s.bio_hep = (f2u(td.x) >> 31) != 0u; s.bio_dist = td.y; }
     if (MODE == 2 || MODE == 3) s.hit = w.hit;
@@ -65,9 +69,9 @@ DEV void unpack_state(const RawState &w, PathState &s) {
     }
 }
 template <int MODE = 0, typename QS>
-DEV void load_state(const QS &q, size_t i, PathState &s) { RawState w; fetch_state<MODE>(q, i, w); unpack_state<MODE>(w, s); }
+DEV void load_state(const QS &q, size_t i, PathState &s, bool compact = false) { RawState w; fetch_state<MODE>(q, i, w, compact); unpack_state<MODE>(w, s, compact); }
 template <int MODE = 0, typename QS>
-DEV void store_state(const QS &q, size_t i, const PathState &s) {
+DEV void store_state(const QS &q, size_t i, const PathState &s, bool compact = false) {
     q.o_maxt[i] = make_float4(s.o.x, s.o.y, s.o.z, MODE == 1 ? s.si_t : (MODE == 0 ? s.ff_t : s.maxt));
     q.d_eta[i] = make_float4(s.d.x, s.d.y, s.d.z, s.eta);
     if (MODE == 3) {
@@ -76,8 +80,14 @@ DEV void store_state(const QS &q, size_t i, const PathState &s) {
         q.w3[i] = make_float4(W[12], W[13], W[14], W[15]); q.w4[i] = make_float4(W[16], W[17], 0.f, 0.f);
     } else q.tp_pdf[i] = make_float4(s.tp.x, s.tp.y, s.tp.z, s.last_pdf);
     q.res_flags[i] = make_float4(s.res.x, s.res.y, s.res.z, u2f(s.flags));
-    q.lp_lane[i] = make_float4(s.lp.x, s.lp.y, s.lp.z, u2f(s.lane));
-    q.rng[i] = make_uint2((uint32_t) s.rng_state, (uint32_t) (s.rng_state >> 32));
+    // Compact records (DRenderParams::compact: the scene has no area emitter, so pdf_emitter_direction never reads the last scatter position): the
+    // lane id and the sampler's TEA word ride with the generator state in one 16-byte word and the position stream is not touched: 80 B
+    // instead of 88, five memory instructions each way instead of six, and no TEA rounds at the start of a trip.
+    if (compact) reinterpret_cast<uint4 *>(q.rng)[i] = make_uint4((uint32_t) s.rng_state, (uint32_t) (s.rng_state >> 32), s.lane, s.rng_word);
+    else {
+        q.lp_lane[i] = make_float4(s.lp.x, s.lp.y, s.lp.z, u2f(s.lane));
+        q.rng[i] = make_uint2((uint32_t) s.rng_state, (uint32_t) (s.rng_state >> 32));
+    }
     if (MODE == 1) q.tdepth[i] = make_float2(s.bio_hep ? -s.tdepth : s.tdepth, s.bio_dist);
     if (MODE == 2 || MODE == 3) q.hit[i] = s.hit;
 }
@@ -106,6 +116,17 @@ template <bool LD>
 DEV SamplerT<LD> lane_rng_resume(RpRef rp, uint32_t lane, uint64_t state) {
     SamplerT<LD> r; r.ld_count = rp.ld_count; r.state = state; r.inc = lane_rng_inc<LD>(rp, lane); r.ld_prepare(); return r;
 }
+// the same from the TEA word a compact record carries (lane_rng_word below)
+template <bool LD>
+DEV SamplerT<LD> lane_rng_resume_word(RpRef rp, uint32_t lane, uint64_t state, uint32_t word) {
+    SamplerT<LD> r; r.ld_count = rp.ld_count; r.state = state;
+    if (LD) {
+        const uint32_t pixel = (rp.log2_spp != 0xffffffffu) ? (lane >> rp.log2_spp) : (lane / rp.spp);
+        r.inc = (uint64_t) word | ((uint64_t) (rp.pass_index * rp.spp + (lane - pixel * rp.spp)) << 32);
+    } else r.inc = ((uint64_t) word << 1) | 1u;
+    r.ld_prepare(); return r;
+}
+template <bool LD> DEV uint32_t lane_rng_word(const SamplerT<LD> &r) { return LD ? (uint32_t) r.inc : (uint32_t) (r.inc >> 1); }
 // Rank-local index of a lane within the current pass (the index space of per-lane buffers)
 DEV uint64_t lane_local_index(RpRef rp, uint32_t lane) {
     if (!rp.pixel_slot) return lane;
@@ -180,7 +201,7 @@ DEV PathState generate_camera_path(SceneRef sc, RpRef rp, const uint32_t *__rest
         flags |= (uint32_t) (sc.cam.medium + 1) << PF_MEDIUM_SHIFT;
         if (rp.integrator == LRT_INTEGRATOR_BIOVOLPATH06) flags |= PF_BIO_EMIT | PF_BIO_FULL;     // biovolpath06.cpp:111 type = 127
     }
-    s.flags = flags; s.rng_state = rng.state;
+    s.flags = flags; s.rng_state = rng.state; s.rng_word = lane_rng_word<LD>(rng);
     return s;
 }
 
@@ -714,7 +735,7 @@ template <typename QS> DEV DPathStreams offset_streams(const QS &q, size_t off) 
 }
 
 // READLANE: how the three regions' slot bases reach the lanes (see below)
-template <int MODE = 0, bool READLANE = true>
+template <int MODE = 0, bool READLANE = true, bool COMPACT = false>
 DEV void retire_and_compact_wave(SceneRef sc, RpRef rp, bool had_path, bool alive, const PathState &s,
                                  float *__restrict__ film, float *__restrict__ sample_out, uint64_t sample_base,
                                  const LRT_CONST DPathStreams &qout, size_t pool, uint32_t P, uint32_t *s_out /* LDS [3] */, StampClock *clk = nullptr) {
@@ -740,7 +761,7 @@ DEV void retire_and_compact_wave(SceneRef sc, RpRef rp, bool had_path, bool aliv
     if (alive) {
         const unsigned long long mine = region == 0 ? m0 : (region == 1 ? m1 : m2);
         const uint32_t slot = b + (uint32_t) __popcll(mine & ((1ull << lane_in_wave) - 1ull));
-        store_state<MODE>(qout, pool + (region == 0 ? slot : (region == 1 ? P + slot : 2u * P - 1u - slot)), s);
+        store_state<MODE>(qout, pool + (region == 0 ? slot : (region == 1 ? P + slot : 2u * P - 1u - slot)), s, COMPACT);
     }
     if (clk) clk->at(6);                                                // (stores issued)
     if (rp.pass_out && had_path && !alive) rp.pass_out[lane_local_index(rp, s.lane)] = s.rng_state;       // next pass continues this stream
@@ -749,7 +770,8 @@ DEV void retire_and_compact_wave(SceneRef sc, RpRef rp, bool had_path, bool aliv
 
 // 4 waves per SIMD (128 VGPRs): one 1024-thread workgroup per CU, or four 256-thread ones.  BLOCK = 512 (one workgroup per CU, 2 waves per
 // SIMD, 256 VGPRs): the wide-record integrators (volpathmis: 18 weights per path), which at 128 registers spill 430 B per lane
-template <int INTEGRATOR, int BLOCK, bool LDS_BVH, bool LD>
+// COMPACT: 80-byte records (store_state): the host launches these instances for scenes without area emitters (DRenderParams::compact)
+template <int INTEGRATOR, int BLOCK, bool LDS_BVH, bool LD, bool COMPACT = false>
 __global__ void __launch_bounds__(BLOCK, BLOCK == 512 ? 2 : (BLOCK == 768 ? 3 : 4))
 k_render(ScenePtr scp, LaunchPtr lp) {
     SceneRef sc = *scp;
@@ -819,7 +841,7 @@ k_render(ScenePtr scp, LaunchPtr lp) {
                 if (t < ta) { i = (t << 6) + lane_in_wave; had_path = i < n_a; }
                 else if (t < ta + tc) { i = ((t - ta) << 6) + lane_in_wave; had_path = i < n_c; i += P; }
                 else { i = ((t - ta - tc) << 6) + lane_in_wave; had_path = i < n_b; i = 2u * P - 1u - i; }
-                if (had_path) { load_state<MODE>(parity ? A.q1 : A.q0, pool + i, s); n_loaded += 1; }
+                if (had_path) { load_state<MODE>(parity ? A.q1 : A.q0, pool + i, s, COMPACT); n_loaded += 1; }
             } else {
                 const uint32_t i = ((t - ta - tc - tb) << 6) + lane_in_wave;
                 had_path = i < fresh;
@@ -829,7 +851,7 @@ k_render(ScenePtr scp, LaunchPtr lp) {
             clk.at(0);                                                  // ticket, index arithmetic, load issue
 #endif
             if (had_path) {
-                SamplerT<LD> rng = lane_rng_resume<LD>(rp, s.lane, s.rng_state);
+                SamplerT<LD> rng = COMPACT ? lane_rng_resume_word<LD>(rp, s.lane, s.rng_state, s.rng_word) : lane_rng_resume<LD>(rp, s.lane, s.rng_state);
 #ifdef LRT_STAMP
                 clk.at(1);                                              // sampler resume (TEA) - needs the lane id: first wait for the record
 #endif
@@ -851,11 +873,11 @@ k_render(ScenePtr scp, LaunchPtr lp) {
                 n_trips += 1;
             }
 #ifdef LRT_STAMP
-            retire_and_compact_wave<MODE, READLANE>(sc, rp, had_path, alive, s, A.film, A.sample_out, A.sample_base, parity ? A.q0 : A.q1, pool, P, s_out, &clk);
+            retire_and_compact_wave<MODE, READLANE, COMPACT>(sc, rp, had_path, alive, s, A.film, A.sample_out, A.sample_base, parity ? A.q0 : A.q1, pool, P, s_out, &clk);
             clk.at(7);                                                  // film sums + atomics
             if (clk.on && lane_in_wave == 0) atomicAdd(&s_stamp[15], 1ull);
 #else
-            retire_and_compact_wave<MODE, READLANE>(sc, rp, had_path, alive, s, A.film, A.sample_out, A.sample_base, parity ? A.q0 : A.q1, pool, P, s_out);
+            retire_and_compact_wave<MODE, READLANE, COMPACT>(sc, rp, had_path, alive, s, A.film, A.sample_out, A.sample_base, parity ? A.q0 : A.q1, pool, P, s_out);
 #endif
             if ((rp.profile & 1u) && lane_in_wave == 0) {
                 const int region = t < ta ? 0 : (t < ta + tc ? 1 : (t < ta + tc + tb ? 2 : 3));

@@ -123,6 +123,28 @@ def test_liver_volpath_hg_and_params_bit_exact(mi, orc):
     assert_lanes_equal(sc, o, center_lane(sc, 16, 0.5), 1 << 15, seed=2)
 
 
+def test_compact_and_wide_records_agree(mi, monkeypatch):
+    """A scene without area emitters queues 80-byte records (no last scatter position, the sampler's TEA word kept instead of recomputed:
+    kernels.h, store_state); LRT_WIDE_RECORDS forces the 88-byte layout.  Same lanes, trips and shadow rays either way, for the independent
+    and the ld sampler, volpath / path / the bio integrators; a scene WITH an area emitter (Cornell) is not affected by the switch."""
+    import os
+    cases = [(LIVER_XML, dict(integrator="volpath", spp=16, res_width=128, res_height=72)), (LIVER_XML, dict(integrator="path", spp=16, res_width=128, res_height=72)),
+             (LIVER_XML, dict(spp=16, res_width=128, res_height=72)), (PARENCHYMA_XML, dict(spp=16, res_width=96, res_height=54)), (MULTIMESH_XML, dict(spp=16, res_width=96, res_height=54))]
+    for path, kw in cases:
+        sc = mi.load_file(path, **kw)
+        n = kw["res_width"] * kw["res_height"] * sc.desc.sample_count
+        monkeypatch.delenv("LRT_WIDE_RECORDS", raising=False)
+        a = sc.render_samples(0, n, seed=3); sa = sc.stats()
+        img_a = sc.render(seed=3)
+        monkeypatch.setenv("LRT_WIDE_RECORDS", "1")
+        b = sc.render_samples(0, n, seed=3); sb = sc.stats()
+        img_b = sc.render(seed=3)
+        monkeypatch.delenv("LRT_WIDE_RECORDS", raising=False)
+        assert (bits(a) == bits(b)).all(), (path, kw)
+        assert sa["n_iter"] == sb["n_iter"] and sa["n_shadow"] == sb["n_shadow"] and sa["n_records"] == sb["n_records"]
+        assert np.isfinite(img_a).all() and np.allclose(img_a, img_b, rtol=2e-4, atol=1e-5)          # film: float atomics in any order
+
+
 def test_realtime_scene_bit_exact(mi, orc):
     sc = mi.load_file(REALTIME_XML, integrator="volpath", spp=4, res_width=192, res_height=108)      # rr_depth = max_depth = 12
     assert_lanes_equal(sc, orc.OrcScene(sc), 0, 192 * 108 * 4)
