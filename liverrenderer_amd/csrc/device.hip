@@ -62,6 +62,7 @@ struct DeviceScene {
     std::vector<DMedium> h_media; DMedium *d_media = nullptr;
     std::vector<DBioMedium> h_bio; DBioMedium *d_bio = nullptr;
     std::vector<DHetMedium> h_het; DHetMedium *d_het = nullptr; std::vector<float *> het_data; bool has_het = false, has_non_bio = false, need_mis = false, mis_alloc = false;
+    bool has_area_emitter = false;         // decides the record layout: only an area emitter's pdf reads the last scatter position (kernels.h, store_state)
     bool prb_null = false;                 // prbvolpath.py:84-91 `handle_null_scattering`: a heterogeneous medium is attached to a shape
     DLdsInfo lds{}; bool use_lds = false; int n_cus = 256; int bvh_leaf = 4;
 
@@ -337,6 +338,8 @@ DeviceScene *device_scene_create(const lrt_scene_desc &d, int device) {
             LRT_SMEM((k_render<LRT_INTEGRATOR_VOLPATHMIS_PLAIN, LRT_WIDE_BLOCK, true, false>)); LRT_SMEM((k_render<LRT_INTEGRATOR_VOLPATHMIS_PLAIN, LRT_WIDE_BLOCK, true, true>));
             LRT_SMEM((k_render_prb<false, 1024, true, false>)); LRT_SMEM((k_render_prb<true, 1024, true, false>));
             LRT_SMEM((k_render_prb<false, 1024, true, true>)); LRT_SMEM((k_render_prb<true, 1024, true, true>));
+            LRT_SMEM((k_render_prb<false, 1024, true, false, false, true>)); LRT_SMEM((k_render_prb<true, 1024, true, false, false, true>));         // (compact records)
+            LRT_SMEM((k_render_prb<false, 1024, true, true, false, true>)); LRT_SMEM((k_render_prb<true, 1024, true, true, false, true>));
             LRT_SMEM((k_render_prb<false, 1024, true, false, true>)); LRT_SMEM((k_render_prb<true, 1024, true, false, true>));
             LRT_SMEM((k_render_prb<false, 1024, true, true, true>)); LRT_SMEM((k_render_prb<true, 1024, true, true, true>));
             LRT_SMEM((k_trace_lds<true>)); LRT_SMEM((k_trace_lds<false>));
@@ -450,6 +453,7 @@ DeviceScene *device_scene_create(const lrt_scene_desc &d, int device) {
         const lrt_emitter_desc &S = d.emitters[i]; DEmitter &o = em[i]; memset(&o, 0, sizeof(o));
         o.type = S.type; o.shape = S.shape; o.scale = S.scale; for (int k = 0; k < 3; ++k) o.radiance[k] = S.radiance[k];
         if (S.type == LRT_EMITTER_AREA) {
+            D->has_area_emitter = true;
             const lrt_shape_desc &sd = d.shapes[S.shape];
             if (sd.kind != LRT_SHAPE_RECTANGLE) throw std::runtime_error("area emitters are supported on rectangle shapes only");
             memcpy(o.to_world, sd.to_world, sizeof(float) * 12);
@@ -700,13 +704,17 @@ static void launch_prb(DeviceScene *D, const DRenderParams &rp, const PoolGeomet
     DLaunch a{}; a.rp = rp; a.li = D->lds; a.q0 = D->q[0]; a.q1 = D->q[1]; a.dl0 = D->dl[0]; a.dl1 = D->dl[1]; a.P = g.P; a.cnt = D->counters;
     a.pixel_list = pixel_list; a.lane_begin = lane_begin; a.n = rp.n_lanes; a.L_buf = L_buf; a.grad_image = grad_image; a.wfilm = D->wfilm; a.grads = grads;
     a.film = film; a.sample_out = sample_out; a.sample_base = lane_begin;
+    const bool compact = D->use_lds && !D->has_area_emitter && !D->prb_null && !getenv("LRT_WIDE_RECORDS");      // compact records as in run_wavefront (homogeneous media, LDS kernels)
+    a.rp.compact = compact ? 1u : 0u;
     const LaunchPtr lp = push_launch(D, a);
 #ifdef LRT_DEV_VOLPATH_ONLY
     (void) lp; throw std::runtime_error("developer build: volpath only");
 #else
     #define LRT_LAUNCH_PRB(BS, LDSB, LD) do { if (D->prb_null) k_render_prb<ADJOINT, BS, LDSB, LD, true><<<g.n_wg, BS, g.smem, st>>>((ScenePtr) D->d_sc, lp); \
                                               else k_render_prb<ADJOINT, BS, LDSB, LD, false><<<g.n_wg, BS, g.smem, st>>>((ScenePtr) D->d_sc, lp); } while (0)
-    if (D->use_lds) { if (rp.ld_count) LRT_LAUNCH_PRB(1024, true, true); else LRT_LAUNCH_PRB(1024, true, false); }
+    if (compact) { if (rp.ld_count) k_render_prb<ADJOINT, 1024, true, true, false, true><<<g.n_wg, 1024, g.smem, st>>>((ScenePtr) D->d_sc, lp);
+                   else k_render_prb<ADJOINT, 1024, true, false, false, true><<<g.n_wg, 1024, g.smem, st>>>((ScenePtr) D->d_sc, lp); }
+    else if (D->use_lds) { if (rp.ld_count) LRT_LAUNCH_PRB(1024, true, true); else LRT_LAUNCH_PRB(1024, true, false); }
     else { if (rp.ld_count) LRT_LAUNCH_PRB(LRT_BLOCK, false, true); else LRT_LAUNCH_PRB(LRT_BLOCK, false, false); }
     #undef LRT_LAUNCH_PRB
 #endif
@@ -750,8 +758,7 @@ static void run_wavefront(DeviceScene *D, const lrt_scene_desc &d, const Resolve
         a.lane_begin = lane_begin; a.n = n_lanes; a.film = film; a.sample_out = sample_out; a.sample_base = lane_begin;
         // Compact records (kernels.h, store_state): only an area emitter's pdf reads the last scatter position, so a scene without one does not queue it.
         // Instances exist for the 1024-thread LDS kernels of path / volpath (homogeneous media) / biovolpath / biovolpath06.  LRT_WIDE_RECORDS: developer switch.
-        bool compact = D->use_lds && !getenv("LRT_WIDE_RECORDS") && O.integrator != LRT_INTEGRATOR_VOLPATHMIS && !(O.integrator == LRT_INTEGRATOR_VOLPATH && D->has_het);
-        for (uint32_t i = 0; i < d.n_emitters; ++i) if (d.emitters[i].type == LRT_EMITTER_AREA) compact = false;
+        const bool compact = D->use_lds && !D->has_area_emitter && !getenv("LRT_WIDE_RECORDS") && O.integrator != LRT_INTEGRATOR_VOLPATHMIS && !(O.integrator == LRT_INTEGRATOR_VOLPATH && D->has_het);
         a.rp.compact = compact ? 1u : 0u;
         const LaunchPtr lp = push_launch(D, a);
 #ifdef LRT_DEV_VOLPATH_ONLY
