@@ -234,7 +234,7 @@ def main():
     rec_b = RECORD_BYTES["volpathmis" if integrator == "volpathmis" else kkey]
     lds = bool(st.get("lds_resident", 1))                      # False: the mesh did not fit the LDS image, BVH in global memory, 256-thread workgroups
     # compact records (kernels.h, store_state): a scene without area emitters does not queue the last scatter position: 8 bytes less per record
-    compact = (lds and kkey in ("path", "volpath", "biovolpath", "biovolpath06", "prbvolpath") and not (backward and has_het) and not os.environ.get("LRT_WIDE_RECORDS")
+    compact = (lds and not backward and kkey in ("path", "volpath", "biovolpath", "biovolpath06") and not os.environ.get("LRT_WIDE_RECORDS")
                and not any(scene.desc.emitters[i].type == _lib.EMITTER["area"] for i in range(scene.desc.n_emitters)))
     if compact: rec_b -= 8
     box = scene.desc.film.rfilter == 0
@@ -255,8 +255,8 @@ def main():
         except Exception:
             pass
     ld = scene.desc.sampler_type == 1
-    geom = "1024, true" if lds else "256, false"
-    kname = ("lrt::k_render_prb<*, %s, %s%s>" % (geom, str(ld).lower(), ", false, true" if compact else "")) if backward else ("lrt::k_render<%d, %s, %s%s>" % (KERNEL_ID[kkey], geom, str(ld).lower(), ", true" if compact else ""))
+    geom = ("768, true" if kkey in ("volpath_het", "volpathmis", "volpathmis_plain") else "1024, true") if lds else "256, false"
+    kname = ("lrt::k_render_prb<*, %s, %s>" % (geom, str(ld).lower())) if backward else ("lrt::k_render<%d, %s, %s%s>" % (KERNEL_ID[kkey], geom, str(ld).lower(), ", true" if compact else ""))
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_file, "kernel_source_id": ksid, "kernel": kname,
                 "launches_per_step": launches / a.steps, "avg_launch_ms": kern_ms / max(launches, 1),

@@ -338,8 +338,6 @@ DeviceScene *device_scene_create(const lrt_scene_desc &d, int device) {
             LRT_SMEM((k_render<LRT_INTEGRATOR_VOLPATHMIS_PLAIN, LRT_WIDE_BLOCK, true, false>)); LRT_SMEM((k_render<LRT_INTEGRATOR_VOLPATHMIS_PLAIN, LRT_WIDE_BLOCK, true, true>));
             LRT_SMEM((k_render_prb<false, 1024, true, false>)); LRT_SMEM((k_render_prb<true, 1024, true, false>));
             LRT_SMEM((k_render_prb<false, 1024, true, true>)); LRT_SMEM((k_render_prb<true, 1024, true, true>));
-            LRT_SMEM((k_render_prb<false, 1024, true, false, false, true>)); LRT_SMEM((k_render_prb<true, 1024, true, false, false, true>));         // (compact records)
-            LRT_SMEM((k_render_prb<false, 1024, true, true, false, true>)); LRT_SMEM((k_render_prb<true, 1024, true, true, false, true>));
             LRT_SMEM((k_render_prb<false, 1024, true, false, true>)); LRT_SMEM((k_render_prb<true, 1024, true, false, true>));
             LRT_SMEM((k_render_prb<false, 1024, true, true, true>)); LRT_SMEM((k_render_prb<true, 1024, true, true, true>));
             LRT_SMEM((k_trace_lds<true>)); LRT_SMEM((k_trace_lds<false>));
@@ -704,17 +702,13 @@ static void launch_prb(DeviceScene *D, const DRenderParams &rp, const PoolGeomet
     DLaunch a{}; a.rp = rp; a.li = D->lds; a.q0 = D->q[0]; a.q1 = D->q[1]; a.dl0 = D->dl[0]; a.dl1 = D->dl[1]; a.P = g.P; a.cnt = D->counters;
     a.pixel_list = pixel_list; a.lane_begin = lane_begin; a.n = rp.n_lanes; a.L_buf = L_buf; a.grad_image = grad_image; a.wfilm = D->wfilm; a.grads = grads;
     a.film = film; a.sample_out = sample_out; a.sample_base = lane_begin;
-    const bool compact = D->use_lds && !D->has_area_emitter && !D->prb_null && !getenv("LRT_WIDE_RECORDS");      // compact records as in run_wavefront (homogeneous media, LDS kernels)
-    a.rp.compact = compact ? 1u : 0u;
-    const LaunchPtr lp = push_launch(D, a);
+    const LaunchPtr lp = push_launch(D, a);             // (compact records, as run_wavefront queues them, were measured on C5: 96-byte records, 5 % SLOWER; the PRB kernels keep the wide layout)
 #ifdef LRT_DEV_VOLPATH_ONLY
     (void) lp; throw std::runtime_error("developer build: volpath only");
 #else
     #define LRT_LAUNCH_PRB(BS, LDSB, LD) do { if (D->prb_null) k_render_prb<ADJOINT, BS, LDSB, LD, true><<<g.n_wg, BS, g.smem, st>>>((ScenePtr) D->d_sc, lp); \
                                               else k_render_prb<ADJOINT, BS, LDSB, LD, false><<<g.n_wg, BS, g.smem, st>>>((ScenePtr) D->d_sc, lp); } while (0)
-    if (compact) { if (rp.ld_count) k_render_prb<ADJOINT, 1024, true, true, false, true><<<g.n_wg, 1024, g.smem, st>>>((ScenePtr) D->d_sc, lp);
-                   else k_render_prb<ADJOINT, 1024, true, false, false, true><<<g.n_wg, 1024, g.smem, st>>>((ScenePtr) D->d_sc, lp); }
-    else if (D->use_lds) { if (rp.ld_count) LRT_LAUNCH_PRB(1024, true, true); else LRT_LAUNCH_PRB(1024, true, false); }
+    if (D->use_lds) { if (rp.ld_count) LRT_LAUNCH_PRB(1024, true, true); else LRT_LAUNCH_PRB(1024, true, false); }
     else { if (rp.ld_count) LRT_LAUNCH_PRB(LRT_BLOCK, false, true); else LRT_LAUNCH_PRB(LRT_BLOCK, false, false); }
     #undef LRT_LAUNCH_PRB
 #endif

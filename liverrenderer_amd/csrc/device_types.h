@@ -185,6 +185,7 @@ struct DPathStreams {
 #define PF_VALID        (1u << 27)
 #define PF_NOHIT        (1u << 28)     // look-ahead proved that the next free-flight segment reaches no surface
 #define PF_BIO_SCATTERED (1u << 29)    // biovolpath06: scattered_chain
+#define PF_LONG_QUERY   (1u << 29)     // biovolpath: the queued record's ray query is unbounded (the competition's distance lies beyond the previous query's hit): queue region L
 #define PF_HAVE_SI      (1u << 29)     // volpath, heterogeneous media: needs_intersection == false, the record's hit stream holds `si`
 #define PF_LAST_NULL    (1u << 30)     // volpathmis: last_event_was_null
 #define PF_BIO_EMIT     (1u << 30)     // biovolpath06: type & 0x0001 (EmittedRadiance)

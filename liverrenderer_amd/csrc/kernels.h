@@ -727,7 +727,9 @@ namespace lrt {
 //   A  [0, n_a)            in-medium paths whose next segment is proven free of surfaces (no ray query)
 //   C  [P, P + n_c)        in-medium paths that need their ray query
 //   B  2P-1-j, j < n_b     paths outside media
-// n_a + n_b + n_c <= P, so the regions never collide.  No cross-workgroup dependency exists besides the lane ticket and the
+//   L  P-1-j, j < n_l      (biovolpath) in-medium paths whose ray query is unbounded: apart from the bounded ones of C, whose traversals are short
+//                          (Liver-MultiMesh with both kinds in one region: 17 of 64 lanes busy in an average traversal step)
+// n_a + n_b + n_c + n_l <= P, so the regions never collide.  No cross-workgroup dependency exists besides the lane ticket and the
 // film atomics; every wave leaves its loops once the ticket is exhausted and its pool is empty.
 template <typename QS> DEV DPathStreams offset_streams(const QS &q, size_t off) {
     DPathStreams r; r.o_maxt = q.o_maxt + off; r.d_eta = q.d_eta + off; r.tp_pdf = q.tp_pdf + off; r.res_flags = q.res_flags + off; r.lp_lane = q.lp_lane + off; r.rng = q.rng + off; r.tdepth = q.tdepth + off; r.hit = q.hit + off; r.w1 = q.w1 + off; r.w2 = q.w2 + off; r.w3 = q.w3 + off; r.w4 = q.w4 + off;
@@ -735,18 +737,20 @@ template <typename QS> DEV DPathStreams offset_streams(const QS &q, size_t off) 
 }
 
 // READLANE: how the three regions' slot bases reach the lanes (see below)
-template <int MODE = 0, bool READLANE = true, bool COMPACT = false>
+template <int MODE = 0, bool READLANE = true, bool COMPACT = false, bool LONGQ = false>
 DEV void retire_and_compact_wave(SceneRef sc, RpRef rp, bool had_path, bool alive, const PathState &s,
                                  float *__restrict__ film, float *__restrict__ sample_out, uint64_t sample_base,
                                  const LRT_CONST DPathStreams &qout, size_t pool, uint32_t P, uint32_t *s_out /* LDS [3] */, StampClock *clk = nullptr) {
     const uint32_t lane_in_wave = threadIdx.x & 63u;
     // survivors first: their stores are the oldest memory operations the next tile's record loads have to wait for (the loads reuse
     // the registers the stores read), so they go out before the film sums, not after them
-    const int region = !(s.flags & PF_MEDIUM_MASK) ? 2 : ((s.flags & PF_NOHIT) ? 0 : 1);
+    // LONGQ (biovolpath): region 3 = L, in-medium paths whose next ray query is unbounded (PF_LONG_QUERY), apart from the bounded ones of region C
+    const int region = !(s.flags & PF_MEDIUM_MASK) ? 2 : ((s.flags & PF_NOHIT) ? 0 : ((LONGQ && (s.flags & PF_LONG_QUERY)) ? 3 : 1));
     const unsigned long long m0 = __ballot(alive && region == 0), m1 = __ballot(alive && region == 1), m2 = __ballot(alive && region == 2);
+    const unsigned long long m3 = LONGQ ? __ballot(alive && region == 3) : 0ull;
     uint32_t base = 0;
-    if (lane_in_wave < 3) {
-        const uint32_t c = (uint32_t) __popcll(lane_in_wave == 0 ? m0 : (lane_in_wave == 1 ? m1 : m2));
+    if (lane_in_wave < (LONGQ ? 4u : 3u)) {
+        const uint32_t c = (uint32_t) __popcll(lane_in_wave == 0 ? m0 : (lane_in_wave == 1 ? m1 : ((!LONGQ || lane_in_wave == 2) ? m2 : m3)));
         if (c) base = atomicAdd(&s_out[lane_in_wave], c);
     }
     // Lanes 0 .. 2 hold the three regions' slot bases.  READLANE: three v_readlane and two selects instead of one shuffle through LDS (ds_bpermute):
@@ -756,12 +760,13 @@ DEV void retire_and_compact_wave(SceneRef sc, RpRef rp, bool had_path, bool aliv
     if (READLANE) {
         const uint32_t b0 = (uint32_t) __builtin_amdgcn_readlane((int) base, 0), b1 = (uint32_t) __builtin_amdgcn_readlane((int) base, 1), b2 = (uint32_t) __builtin_amdgcn_readlane((int) base, 2);
         b = region == 0 ? b0 : (region == 1 ? b1 : b2);
+        if (LONGQ) { const uint32_t b3 = (uint32_t) __builtin_amdgcn_readlane((int) base, 3); if (region == 3) b = b3; }
     } else b = __shfl(base, region);
     if (clk) clk->at(5);                                                // (developer section timer: ballots, slot counters)
     if (alive) {
-        const unsigned long long mine = region == 0 ? m0 : (region == 1 ? m1 : m2);
+        const unsigned long long mine = region == 0 ? m0 : (region == 1 ? m1 : ((!LONGQ || region == 2) ? m2 : m3));
         const uint32_t slot = b + (uint32_t) __popcll(mine & ((1ull << lane_in_wave) - 1ull));
-        store_state<MODE>(qout, pool + (region == 0 ? slot : (region == 1 ? P + slot : 2u * P - 1u - slot)), s, COMPACT);
+        store_state<MODE>(qout, pool + (region == 0 ? slot : (region == 1 ? P + slot : ((!LONGQ || region == 2) ? 2u * P - 1u - slot : P - 1u - slot))), s, COMPACT);
     }
     if (clk) clk->at(6);                                                // (stores issued)
     if (rp.pass_out && had_path && !alive) rp.pass_out[lane_local_index(rp, s.lane)] = s.rng_state;       // next pass continues this stream
@@ -780,7 +785,7 @@ k_render(ScenePtr scp, LaunchPtr lp) {
     const LRT_CONST DLdsInfo &li = A.li;
     const uint32_t P = A.P;
     extern __shared__ __align__(16) unsigned char smem[];
-    __shared__ uint32_t s_in[3], s_out[3], s_ticket, s_fresh;
+    __shared__ uint32_t s_in[4], s_out[4], s_ticket, s_fresh;
     __shared__ unsigned long long s_fresh_base, s_prof[8];
 #ifdef LRT_STAMP
     __shared__ unsigned long long s_stamp[16];
@@ -788,6 +793,7 @@ k_render(ScenePtr scp, LaunchPtr lp) {
 #endif
     const uint32_t tid = threadIdx.x, lane_in_wave = tid & 63u;
     constexpr bool READLANE = INTEGRATOR != LRT_INTEGRATOR_PATH && INTEGRATOR != LRT_INTEGRATOR_BIOVOLPATH06;
+    constexpr bool LONGQ = INTEGRATOR == LRT_INTEGRATOR_BIOVOLPATH;          // fourth queue region (retire_and_compact_wave)
     constexpr int MODE = (INTEGRATOR == LRT_INTEGRATOR_BIOVOLPATH || INTEGRATOR == LRT_INTEGRATOR_BIOVOLPATH06) ? 1 : (INTEGRATOR == LRT_INTEGRATOR_VOLPATH_HET ? 2 : ((INTEGRATOR == LRT_INTEGRATOR_VOLPATHMIS || INTEGRATOR == LRT_INTEGRATOR_VOLPATHMIS_PLAIN) ? 3 : 0));
     if (tid < 8) s_prof[tid] = 0;
     const unsigned long long t_wg_start = (rp.profile & 1u) ? wall_clock64() : 0ull;
@@ -804,27 +810,28 @@ k_render(ScenePtr scp, LaunchPtr lp) {
     const GlobalTracer tr_glb{ sc, reinterpret_cast<int *>(smem) + tid };
     const size_t pool = (size_t) blockIdx.x * 2u * P;
     uint32_t parity = 0;                                      // queue the round reads: parity ? A.q1 : A.q0 (the stream pointers are scalar loads at the point of use)
-    if (tid == 0) { s_in[0] = s_in[1] = s_in[2] = 0; }
+    if (tid == 0) { s_in[0] = s_in[1] = s_in[2] = 0; if (LONGQ) s_in[3] = 0; }
     bool lanes_left = true;                                   // thread 0
     uint32_t n_shadow = 0, n_extra = 0, n_trips = 0, n_loaded = 0;
     if (rp.profile & 1u) t_loop_start = wall_clock64();
     for (;;) {
         if (tid == 0) {
-            const uint32_t want = P - (s_in[0] + s_in[1] + s_in[2]);
+            const uint32_t want = P - (s_in[0] + s_in[1] + s_in[2] + (LONGQ ? s_in[3] : 0u));
             uint32_t got = 0; unsigned long long base = 0;
             if (want && lanes_left) {
                 base = atomicAdd(&A.cnt->next_lane, (unsigned long long) want);
                 if (base < rp.n_lanes) got = (uint32_t) (rp.n_lanes - base < (unsigned long long) want ? rp.n_lanes - base : (unsigned long long) want);
                 lanes_left = base + want < rp.n_lanes;
             }
-            s_fresh = got; s_fresh_base = base; s_ticket = 0; s_out[0] = s_out[1] = s_out[2] = 0;
+            s_fresh = got; s_fresh_base = base; s_ticket = 0; s_out[0] = s_out[1] = s_out[2] = 0; if (LONGQ) s_out[3] = 0;
         }
         __syncthreads();
-        const uint32_t n_a = s_in[0], n_c = s_in[1], n_b = s_in[2], fresh = s_fresh;
+        const uint32_t n_a = s_in[0], n_c = s_in[1], n_b = s_in[2], n_l = LONGQ ? s_in[3] : 0u, fresh = s_fresh;
         const unsigned long long fresh_base = s_fresh_base;
-        if (n_a + n_c + n_b + fresh == 0) break;
+        if (n_a + n_c + n_b + n_l + fresh == 0) break;
         const uint32_t ta = (n_a + 63u) >> 6, tc = (n_c + 63u) >> 6, tb = (n_b + 63u) >> 6, tf = (fresh + 63u) >> 6;
-        const uint32_t n_tiles = ta + tc + tb + tf;
+        const uint32_t tcl = tc + (LONGQ ? (n_l + 63u) >> 6 : 0u);          // tiles of C, then of L
+        const uint32_t n_tiles = ta + tcl + tb + tf;
         for (;;) {
             uint32_t t = 0;
             if (lane_in_wave == 0) t = atomicAdd(&s_ticket, 1u);            // (tickets of 2 or 4 consecutive tiles, one LDS round trip each, and the next tile's ticket drawn before the compaction: measured, no better)
@@ -832,18 +839,19 @@ k_render(ScenePtr scp, LaunchPtr lp) {
             if (t >= n_tiles) break;
             const unsigned long long t_begin = (rp.profile & 1u) ? wall_clock64() : 0ull;
 #ifdef LRT_STAMP
-            StampClock clk; clk.start(s_stamp, LRT_STAMP_KIND == 0 ? t < ta : (LRT_STAMP_KIND == 1 ? (t >= ta && t < ta + tc) : (LRT_STAMP_KIND == 2 ? (t >= ta + tc && t < ta + tc + tb) : t >= ta + tc + tb)));
+            StampClock clk; clk.start(s_stamp, LRT_STAMP_KIND == 0 ? t < ta : (LRT_STAMP_KIND == 1 ? (t >= ta && t < ta + tcl) : (LRT_STAMP_KIND == 2 ? (t >= ta + tcl && t < ta + tcl + tb) : t >= ta + tcl + tb)));
 #endif
             bool had_path = false, alive = false;
             PathState s; s.flags = 0; s.lane = 0; s.res = V3(0.f);
-            if (t < ta + tc + tb) {
+            if (t < ta + tcl + tb) {
                 uint32_t i;
                 if (t < ta) { i = (t << 6) + lane_in_wave; had_path = i < n_a; }
                 else if (t < ta + tc) { i = ((t - ta) << 6) + lane_in_wave; had_path = i < n_c; i += P; }
-                else { i = ((t - ta - tc) << 6) + lane_in_wave; had_path = i < n_b; i = 2u * P - 1u - i; }
+                else if (LONGQ && t < ta + tcl) { i = ((t - ta - tc) << 6) + lane_in_wave; had_path = i < n_l; i = P - 1u - i; }
+                else { i = ((t - ta - tcl) << 6) + lane_in_wave; had_path = i < n_b; i = 2u * P - 1u - i; }
                 if (had_path) { load_state<MODE>(parity ? A.q1 : A.q0, pool + i, s, COMPACT); n_loaded += 1; }
             } else {
-                const uint32_t i = ((t - ta - tc - tb) << 6) + lane_in_wave;
+                const uint32_t i = ((t - ta - tcl - tb) << 6) + lane_in_wave;
                 had_path = i < fresh;
                 if (had_path) s = generate_camera_path<LD>(sc, rp, A.pixel_list, A.lane_begin + fresh_base + i);
             }
@@ -856,13 +864,13 @@ k_render(ScenePtr scp, LaunchPtr lp) {
                 clk.at(1);                                              // sampler resume (TEA) - needs the lane id: first wait for the record
 #endif
                 if (INTEGRATOR == LRT_INTEGRATOR_PATH) alive = LDS_BVH ? path_iteration(sc, rp, s, rng, tr_lds, n_shadow) : path_iteration(sc, rp, s, rng, tr_glb, n_shadow);
-                else if (INTEGRATOR == LRT_INTEGRATOR_BIOVOLPATH) { const bool fresh_tile = t >= ta + tc + tb; alive = LDS_BVH ? biovolpath_iteration(sc, rp, s, rng, tr_lds, n_shadow, n_extra, fresh_tile) : biovolpath_iteration(sc, rp, s, rng, tr_glb, n_shadow, n_extra, fresh_tile); }
+                else if (INTEGRATOR == LRT_INTEGRATOR_BIOVOLPATH) { const bool fresh_tile = t >= ta + tcl + tb; alive = LDS_BVH ? biovolpath_iteration(sc, rp, s, rng, tr_lds, n_shadow, n_extra, fresh_tile) : biovolpath_iteration(sc, rp, s, rng, tr_glb, n_shadow, n_extra, fresh_tile); }
                 else if (INTEGRATOR == LRT_INTEGRATOR_BIOVOLPATH06) alive = LDS_BVH ? biovolpath06_iteration(sc, rp, s, rng, tr_lds) : biovolpath06_iteration(sc, rp, s, rng, tr_glb);
                 else if (INTEGRATOR == LRT_INTEGRATOR_VOLPATHMIS) alive = LDS_BVH ? volpathmis_iteration<true>(sc, rp, s, rng, tr_lds, n_shadow) : volpathmis_iteration<true>(sc, rp, s, rng, tr_glb, n_shadow);
                 else if (INTEGRATOR == LRT_INTEGRATOR_VOLPATHMIS_PLAIN) alive = LDS_BVH ? volpathmis_iteration<false>(sc, rp, s, rng, tr_lds, n_shadow) : volpathmis_iteration<false>(sc, rp, s, rng, tr_glb, n_shadow);
                 else if (INTEGRATOR == LRT_INTEGRATOR_VOLPATH_HET) alive = LDS_BVH ? volpath_iteration<true>(sc, rp, s, rng, tr_lds, n_shadow, n_extra) : volpath_iteration<true>(sc, rp, s, rng, tr_glb, n_shadow, n_extra);
                 else {
-                    const bool fresh_tile = t >= ta + tc + tb;
+                    const bool fresh_tile = t >= ta + tcl + tb;
 #ifdef LRT_STAMP
                     alive = LDS_BVH ? volpath_iteration<false>(sc, rp, s, rng, tr_lds, n_shadow, n_extra, fresh_tile, &clk) : volpath_iteration<false>(sc, rp, s, rng, tr_glb, n_shadow, n_extra, fresh_tile, &clk);
 #else
@@ -873,21 +881,21 @@ k_render(ScenePtr scp, LaunchPtr lp) {
                 n_trips += 1;
             }
 #ifdef LRT_STAMP
-            retire_and_compact_wave<MODE, READLANE, COMPACT>(sc, rp, had_path, alive, s, A.film, A.sample_out, A.sample_base, parity ? A.q0 : A.q1, pool, P, s_out, &clk);
+            retire_and_compact_wave<MODE, READLANE, COMPACT, LONGQ>(sc, rp, had_path, alive, s, A.film, A.sample_out, A.sample_base, parity ? A.q0 : A.q1, pool, P, s_out, &clk);
             clk.at(7);                                                  // film sums + atomics
             if (clk.on && lane_in_wave == 0) atomicAdd(&s_stamp[15], 1ull);
 #else
-            retire_and_compact_wave<MODE, READLANE, COMPACT>(sc, rp, had_path, alive, s, A.film, A.sample_out, A.sample_base, parity ? A.q0 : A.q1, pool, P, s_out);
+            retire_and_compact_wave<MODE, READLANE, COMPACT, LONGQ>(sc, rp, had_path, alive, s, A.film, A.sample_out, A.sample_base, parity ? A.q0 : A.q1, pool, P, s_out);
 #endif
             if ((rp.profile & 1u) && lane_in_wave == 0) {
-                const int region = t < ta ? 0 : (t < ta + tc ? 1 : (t < ta + tc + tb ? 2 : 3));
+                const int region = t < ta ? 0 : (t < ta + tcl ? 1 : (t < ta + tcl + tb ? 2 : 3));
                 atomicAdd(&s_prof[region], wall_clock64() - t_begin); atomicAdd(&s_prof[4 + region], 1ull);
             }
         }
         { const unsigned long long tb0 = (rp.profile & 1u) ? wall_clock64() : 0ull;
         __syncthreads();
         if (rp.profile & 1u) t_barrier += wall_clock64() - tb0; }
-        if (tid == 0) { s_in[0] = s_out[0]; s_in[1] = s_out[1]; s_in[2] = s_out[2]; }
+        if (tid == 0) { s_in[0] = s_out[0]; s_in[1] = s_out[1]; s_in[2] = s_out[2]; if (LONGQ) s_in[3] = s_out[3]; }
         parity ^= 1u;
     }
     if ((rp.profile & 1u) && (tid & 63u) == 0) {              // workgroup timeline; barrier waits summed over the 16 waves' first lanes

@@ -181,16 +181,15 @@ DEV bool biovolpath_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, con
         return a && depth < max_depth;
     };
     // inside a medium: the free-flight draw of the trip about to run, its element competition, and the attempt to prove the segment free
-    uint32_t nohit = 0;
+    uint32_t nohit = 0, longq = 0;
     float cache_dist = u2f(0x7fc00000u); bool cache_hep = false;
     auto free_flight_stage = [&]() {
         if (medium < 0) return;
         int type2; float dist2;
         bio_compute_distance(sc.bio[medium], channel, rng.next(), tissue_depth, type2, dist2);
-        if (sc.grid.enabled) {
-            const BioMI m2 = bio_finish_interaction<true>(sc.bio[medium], ray.o, ray.d, si_t, channel, type2, dist2);
-            if (m2.valid() && segment_free_of_surfaces(sc.grid, ray.o, ray.d, m2.t)) nohit = PF_NOHIT;
-        }
+        const BioMI m2 = bio_finish_interaction<true>(sc.bio[medium], ray.o, ray.d, si_t, channel, type2, dist2);
+        if (sc.grid.enabled && m2.valid() && segment_free_of_surfaces(sc.grid, ray.o, ray.d, m2.t)) nohit = PF_NOHIT;
+        if (!m2.valid()) longq = PF_LONG_QUERY;                         // the next trip's query runs to the largest float: its own queue region (k_render)
         cache_dist = dist2 == dist2 ? dist2 : kInf; cache_hep = type2 == BIO_ABSORBER_AND_ATTENUATOR;   // kept in the record: the next trip starts from it
     };
     if (fresh) {
@@ -200,7 +199,7 @@ DEV bool biovolpath_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, con
             commit(); return false;
         }
         free_flight_stage(); bio_dist = cache_dist; bio_hep = cache_hep; proven_empty = nohit != 0;
-        nohit = 0; cache_dist = u2f(0x7fc00000u); cache_hep = false;
+        nohit = 0; longq = 0; cache_dist = u2f(0x7fc00000u); cache_hep = false;
     }
     bool active = true;
     bool active_medium = medium >= 0, active_surface = !active_medium;
@@ -310,7 +309,7 @@ DEV bool biovolpath_iteration(SceneRef sc, RpRef rp, PathState &s, SMP &rng, con
         else free_flight_stage();
     }
     commit();
-    s.flags |= nohit; s.bio_dist = cache_dist; s.bio_hep = cache_hep;
+    s.flags |= nohit | longq; s.bio_dist = cache_dist; s.bio_hep = cache_hep;
     return active;
 }
 

@@ -351,7 +351,7 @@ DEV V3 lane_delta_L(SceneRef sc, RpRef rp, uint32_t lane, const float *__restric
 //                   accumulated per workgroup in f64 (LDS) and added to grads[7] once at the end.
 // 4 waves per SIMD for every variant (128 VGPRs): one 1024-thread workgroup per CU, or four 256-thread ones
 // HET: the scene holds a heterogeneous medium: null collisions (prb_iteration<.., true>), 120-B records (+ the kept surface hit)
-template <bool ADJOINT, int BLOCK, bool LDS_BVH, bool LD, bool HET = false, bool COMPACT = false>        // COMPACT: 96-byte records (kernels.h, store_state)
+template <bool ADJOINT, int BLOCK, bool LDS_BVH, bool LD, bool HET = false>
 __global__ void __launch_bounds__(BLOCK, 4)
 k_render_prb(ScenePtr scp, LaunchPtr lp) {
     constexpr int MODE = HET ? 2 : 0;
@@ -413,7 +413,7 @@ k_render_prb(ScenePtr scp, LaunchPtr lp) {
                 if (t < ta) { i = (t << 6) + lane_in_wave; had_path = i < n_a; }
                 else if (t < tm) { i = ((t - ta) << 6) + lane_in_wave; had_path = i < n_c; i += P; }
                 else { i = ((t - tm) << 6) + lane_in_wave; had_path = i < n_s; i = 2u * P - 1u - i; }
-                if (had_path) { load_state<MODE>(parity ? A.q1 : A.q0, pool + i, s, COMPACT); dl = (parity ? A.dl1 : A.dl0)[pool + i]; n_loaded += 1; }
+                if (had_path) { load_state<MODE>(parity ? A.q1 : A.q0, pool + i, s); dl = (parity ? A.dl1 : A.dl0)[pool + i]; n_loaded += 1; }
             } else {
                 const uint32_t i = ((t - tm - ts) << 6) + lane_in_wave;
                 had_path = i < fresh;
@@ -428,7 +428,7 @@ k_render_prb(ScenePtr scp, LaunchPtr lp) {
             }
             PrbGrads G; G.sigma_t[0] = G.sigma_t[1] = G.sigma_t[2] = G.albedo[0] = G.albedo[1] = G.albedo[2] = G.g = 0.f;
             if (had_path) {
-                SamplerT<LD> rng = COMPACT ? lane_rng_resume_word<LD>(rp, s.lane, s.rng_state, s.rng_word) : lane_rng_resume<LD>(rp, s.lane, s.rng_state);
+                SamplerT<LD> rng = lane_rng_resume<LD>(rp, s.lane, s.rng_state);
                 alive = LDS_BVH ? prb_iteration<ADJOINT, HET>(sc, rp, s, rng, tr_lds, n_shadow, V3(dl.x, dl.y, dl.z), G)
                                 : prb_iteration<ADJOINT, HET>(sc, rp, s, rng, tr_glb, n_shadow, V3(dl.x, dl.y, dl.z), G);
                 s.rng_state = rng.state;
@@ -455,7 +455,7 @@ k_render_prb(ScenePtr scp, LaunchPtr lp) {
             if (alive) {
                 const uint32_t slot = b + (uint32_t) __popcll((region == 0 ? m0 : (region == 1 ? m1 : m2)) & ((1ull << lane_in_wave) - 1ull));
                 const uint32_t rec = region == 0 ? slot : (region == 1 ? P + slot : 2u * P - 1u - slot);
-                store_state<MODE>(parity ? A.q0 : A.q1, pool + rec, s, COMPACT); (parity ? A.dl0 : A.dl1)[pool + rec] = dl;
+                store_state<MODE>(parity ? A.q0 : A.q1, pool + rec, s); (parity ? A.dl0 : A.dl1)[pool + rec] = dl;
             }
         }
         __syncthreads();

@@ -3,7 +3,7 @@
 # For each library: per-lane parity of a small volpath render against the oracle, then bench.py --config c3 (alternating, 2 rounds).
 CFG=${CFG:-c3}
 for so in "$@"; do
-  LRT_LIBRARY=$PWD/$so python3 scripts/dev_parity.py || echo "PARITY FAILED for $so"
+  DEV_SCENE=$CFG LRT_LIBRARY=$PWD/$so python3 scripts/dev_parity.py || echo "PARITY FAILED for $so"
 done
 for rep in 1 2; do
   for so in "$@"; do

@@ -1,4 +1,4 @@
-"""Per-lane parity of the library named by LRT_LIBRARY against the oracle on small volpath renders (developer A/B aid)."""
+"""Per-lane parity of the library named by LRT_LIBRARY against the oracle on small volpath renders (developer A/B aid; DEV_SCENE=multimesh: Liver-MultiMesh with its own defaults)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -6,9 +6,12 @@ import numpy as np
 import liverrenderer_amd as mi
 import orc
 xml = os.path.join(ROOT, "scenes", "Liver-SingleMesh", "mitsuba3", "scene.xml")
+kw = dict(integrator="volpath")
+if os.environ.get("DEV_SCENE") == "multimesh":                 # a developer build of the biovolpath / ld kernel: the scene's own defaults
+    xml = os.path.join(ROOT, "scenes", "Liver-MultiMesh", "mitsuba3", "scene_temp.xml"); kw = {}
 ok = True
 for (w, h, spp, seed) in ((128, 72, 16, 0), (96, 54, 64, 3)):
-    sc = mi.load_file(xml, integrator="volpath", spp=spp, res_width=w, res_height=h)
+    sc = mi.load_file(xml, spp=spp, res_width=w, res_height=h, **kw)
     n = w * h * spp
     g = sc.render_samples(0, n, seed=seed); st = sc.stats()
     o = orc.OrcScene(sc); c = o.render_samples(0, n, seed=seed)

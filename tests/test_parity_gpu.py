@@ -143,16 +143,6 @@ def test_compact_and_wide_records_agree(mi, monkeypatch):
         assert (bits(a) == bits(b)).all(), (path, kw)
         assert sa["n_iter"] == sb["n_iter"] and sa["n_shadow"] == sb["n_shadow"] and sa["n_records"] == sb["n_records"]
         assert np.isfinite(img_a).all() and np.allclose(img_a, img_b, rtol=2e-4, atol=1e-5)          # film: float atomics in any order
-    # the PRB adjoint (96-byte compact records): same trips, gradients equal up to the order of the sums
-    sc = mi.load_file(LIVER_XML, integrator="prbvolpath", spp=8, res_width=96, res_height=54)
-    h, w, c = sc.film_shape()
-    grad = np.ones((h, w, c - 1), np.float32) / (h * w * (c - 1))
-    ga = sc.render_backward(grad, seed=2); sa = sc.stats()
-    monkeypatch.setenv("LRT_WIDE_RECORDS", "1")
-    gb = sc.render_backward(grad, seed=2); sb = sc.stats()
-    monkeypatch.delenv("LRT_WIDE_RECORDS", raising=False)
-    assert sa["n_iter"] == sb["n_iter"] and sa["n_shadow"] == sb["n_shadow"]
-    for k in ga: assert np.allclose(np.asarray(ga[k], np.float64), np.asarray(gb[k], np.float64), rtol=1e-5, atol=1e-12), k
 
 
 def test_realtime_scene_bit_exact(mi, orc):
