@@ -303,7 +303,7 @@ def main():
             hg.render_to_device(film.data_ptr(), image.data_ptr(), spp=spp, seed=i, device=local_rank)
             hs = hg.stats(); hk += hs["kernel_ms"]; hi += hs["n_iter"]; hr += hs["n_records"]
         torch.cuda.synchronize(); hdt = (time.perf_counter() - t1) / a.steps
-        hb = 2.0 * RECORD_BYTES["volpath"] * hr + 4.0 * C * w * h * a.steps
+        hb = 2.0 * rec_b * hr + 4.0 * C * w * h * a.steps                 # (same scene, same record layout as the main leg)
         out["hg_phase"] = {"value": round(n_samples / hdt / 1e6, 3), "unit": "Msamples/s", "ms_per_step": round(hdt * 1e3, 3), "g": 0.7,
                            "workload": CONFIGS["c3hg"]["label"].format(integrator=integrator, w=w, h=h, spp=spp),
                            "roofline_frac": round(hb / (hk * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if hk > 0 else None,
