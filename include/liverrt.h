@@ -163,7 +163,7 @@ typedef struct {
 
 typedef struct {
     int32_t type;             /* LRT_INTEGRATOR_*                                  */
-    int32_t max_depth;        /* -1: unbounded                                     */
+    int32_t max_depth;        /* -1: unbounded = 65535 (so is any larger value)    */
     int32_t rr_depth;
     int32_t hide_emitters;
 } lrt_integrator_desc;

@@ -681,8 +681,13 @@ static void volpath_sample(Ctx &C, Ray ray, int medium, V3 *out, bool *out_valid
     V3 last_scatter_p(0.f);
     float last_scatter_direction_pdf = 1.f;
     const uint32_t max_depth = (uint32_t) C.max_depth;
+    static const long trace_after = getenv("ORC_TRACE_AFTER") ? atol(getenv("ORC_TRACE_AFTER")) : -1;      /* developer aid: print a path's trips beyond this count */
+    uint64_t trips = 0;
     while (active) {
-        C.n_iter++;
+        C.n_iter++; ++trips;
+        if (trace_after >= 0 && (long) trips > trace_after && (long) trips <= trace_after + 12)
+            fprintf(stderr, "[orc trace] trip %llu depth %u medium %d tp %g %g %g eta %g o %g %g %g d %g %g %g maxt %g si.t %g needs_isect %d\n", (unsigned long long) trips, depth, medium,
+                    throughput.x, throughput.y, throughput.z, eta, ray.o.x, ray.o.y, ray.o.z, ray.d.x, ray.d.y, ray.d.z, ray.maxt, si.t, (int) needs_intersection);
         active = any_nonzero(throughput);
         float q = fminf(max3(throughput) * sqr(eta), .95f);
         bool perform_rr = depth > (uint32_t) C.rr_depth;
@@ -1198,6 +1203,7 @@ static Opts resolve_opts(const Scene &S, const lrt_render_opts *o) {
     Opts r;
     r.integrator = (o && o->integrator >= 0) ? o->integrator : S.d.integrator.type;
     r.max_depth = (o && o->max_depth != -2) ? o->max_depth : S.d.integrator.max_depth;
+    if (r.max_depth < 0 || r.max_depth > 65535) r.max_depth = 65535;        /* the product's reading of "unbounded" (device.hip, resolve): 16-bit depth field, and an end for paths Russian roulette cannot stop */
     r.rr_depth = (o && o->rr_depth >= 0) ? o->rr_depth : S.d.integrator.rr_depth;
     r.hide_emitters = (o && o->hide_emitters >= 0) ? (o->hide_emitters != 0) : (S.d.integrator.hide_emitters != 0);
     r.spp = (o && o->spp) ? o->spp : S.d.sample_count;
